@@ -1,0 +1,196 @@
+/*
+ * rtmi.h -- C ABI of the MI355X (gfx950) render core for nealsid/RayTracer scenes.
+ *
+ * The reference exposes no FFI; its seam is the Swift function
+ *   raytraceWorld(camera:cameraDirection:focalLength:imageWidthPixels:imageHeightPixels:
+ *                 ambientLight:lights:objects:materialDictionary:outputBitmap:pixelDone:)
+ * (RayTraceUI/RayTracingFunctions.swift:145-180) and, below it, raytracePixels
+ * (RayTracingFunctions.swift:59-114).  Every entry point here replaces a piece of that
+ * seam; the citation on each declaration names the reference code it stands in for.
+ *
+ * All structs are plain-old-data with explicit padding; all reals are IEEE binary64,
+ * exactly the values the reference's structs hold.  No torch / C++ types cross this
+ * boundary.  Functions return RTMI_OK (0) or a negative rtmi_status.
+ */
+#ifndef RTMI_H
+#define RTMI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTMI_ABI_VERSION 1
+
+typedef enum {
+  RTMI_OK = 0,
+  RTMI_ERR_INVALID_ARGUMENT = -1, /* null pointer, bad size, bad index                       */
+  RTMI_ERR_UNSUPPORTED = -2,      /* legal reference input this build does not handle        */
+  RTMI_ERR_NO_DEVICE = -3,        /* no usable gfx950 device / HIP runtime failure at init   */
+  RTMI_ERR_HIP = -4,              /* a HIP call failed; see rtmi_last_error()                */
+  RTMI_ERR_OUT_OF_MEMORY = -5
+} rtmi_status;
+
+/* Camera: the three values typed into the reference UI (ViewController.swift:142-148) plus
+ * the focal-length slider (ViewController.swift:38).  dir is NOT normalised by the caller
+ * and not by the callee either (RayTracingFunctions.swift:156). */
+typedef struct {
+  double pos[3];
+  double dir[3];
+  double focal_length;
+} rtmi_camera;
+
+/* PointLight stored properties (Renderables.swift:35-37). */
+typedef struct {
+  double loc[3];
+  double specular[3];
+  double diffuse[3];
+} rtmi_light;
+
+/* Material (ObjLoader.swift:52-59).  d and illum are carried but unused by shading. */
+typedef struct {
+  double Ns;
+  double d;
+  int32_t illum;
+  int32_t pad_;
+  double Kd[3];
+  double Ka[3];
+  double Ks[3];
+} rtmi_material;
+
+/* Triangle: three explicit FP64 vertices, as createTriangleList builds them
+ * (ViewController.swift:107-120), plus a material index (-1 = nil, which is what the
+ * reference passes; Renderables.swift:116). */
+typedef struct {
+  double v[3][3];
+  int32_t material;
+  int32_t pad_;
+} rtmi_triangle;
+
+typedef enum {
+  RTMI_SPHERE = 0,          /* Sphere(center, radius)            Renderables.swift:207-213 */
+  RTMI_TRIANGLES = 1,       /* a run of `count` Triangle objects occupying consecutive
+                               positions of the top-level list   Renderables.swift:115-167 */
+  RTMI_BOUNDING_SPHERE = 2, /* Sphere(boundingObjects:)          Renderables.swift:215-246 */
+  RTMI_LIGHT = 3            /* a PointLight placed in `objects`  Renderables.swift:80-91   */
+} rtmi_kind;
+
+/* One entry of the ordered top-level `objects` array handed to raytraceWorld
+ * (RayTracingFunctions.swift:152).  Order is significant: the reference takes the first
+ * intersection in list order, not the nearest (RayTracingFunctions.swift:41-43, :83). */
+typedef struct {
+  int32_t kind;     /* rtmi_kind */
+  int32_t material; /* SPHERE / BOUNDING_SPHERE: material index or -1 (nil) */
+  double center[3]; /* SPHERE / BOUNDING_SPHERE */
+  double radius;    /* SPHERE / BOUNDING_SPHERE; radiusSquared is derived as radius*radius */
+  int64_t first;    /* TRIANGLES / BOUNDING_SPHERE: first index into triangles[]; LIGHT: light index */
+  int64_t count;    /* TRIANGLES / BOUNDING_SPHERE: number of triangles */
+} rtmi_object;
+
+typedef struct {
+  const rtmi_light* lights;
+  int32_t n_lights;
+  int32_t n_materials;
+  const rtmi_material* materials;
+  const rtmi_object* objects;
+  const rtmi_triangle* triangles;
+  int64_t n_objects;
+  int64_t n_triangles;
+} rtmi_scene_desc;
+
+typedef enum {
+  RTMI_HIT_LIST_ORDER = 0 /* reference-exact: lowest list position that is hit */
+} rtmi_hit_policy;
+
+/* Render parameters.  width/height are the globals imageWidth/imageHeight
+ * (ViewController.swift:13-14); the reference renders pixels [0,W-1) x [0,H-1)
+ * (RayTracingFunctions.swift:170, WorldCoordinateSequence.swift:69-87).
+ * pixel_subdivision is WorldCoordinateSequence.pixelSubdivision (1, 0.5, 0.25 ...).
+ * The pixel window and the cyclic tile selection restrict WHICH of those pixels are
+ * rendered; pixel->world scaling always uses the full-frame constants. */
+typedef struct {
+  int32_t width;
+  int32_t height;
+  double pixel_subdivision;
+  double ambient[3];
+  int32_t hit_policy;
+  int32_t x0, y0, x1, y1; /* window, ends exclusive; all zero = (0,0,W-1,H-1) */
+  int32_t tile_size;      /* square tile edge in pixels; 0 = no tiling */
+  int32_t tile_rank;      /* render tiles whose id % tile_world == tile_rank */
+  int32_t tile_world;     /* <= 1 = every tile */
+  int32_t pad_;
+} rtmi_params;
+
+/* Work and timing counters of one render call. */
+typedef struct {
+  int64_t samples;          /* primary rays generated                                    */
+  int64_t rays_reflection;  /* RayTracingFunctions.swift:212                             */
+  int64_t rays_shadow;      /* RayTracingFunctions.swift:236                             */
+  int64_t tri_tests;        /* (ray, triangle) pairs evaluated                           */
+  int64_t sphere_tests;     /* (ray, sphere|light) pairs evaluated                       */
+  int64_t tri_exact_tests;  /* pairs that went through the FP64 reference-order test     */
+  int64_t primary_hits;     /* samples that were shaded                                  */
+  int64_t reserved_[3];
+  double ms_total;          /* device time of the whole call (HIP events)                */
+  double ms_tri_search;     /* device time of the triangle search launches only          */
+  int64_t tri_search_launches;
+  int64_t tri_tests_primary_kernel; /* pairs evaluated by the common-origin kernel       */
+  double ms_primary_kernel; /* its accumulated launch time                               */
+} rtmi_counters;
+
+typedef struct rtmi_scene rtmi_scene;
+
+/* ABI version of the loaded library (== RTMI_ABI_VERSION of the header it was built from). */
+int32_t rtmi_abi_version(void);
+
+/* Human-readable text for a status code; never NULL. */
+const char* rtmi_status_string(int32_t status);
+
+/* Text of the last HIP failure on the calling thread ("" if none). */
+const char* rtmi_last_error(void);
+
+/* Number of gfx950 devices visible to the process, or a negative rtmi_status. */
+int32_t rtmi_device_count(void);
+
+/* Sphere(boundingObjects:) for a triangle list: centre = AABB midpoint, radius = half the
+ * largest axis extent (Renderables.swift:215-246 with Triangle.getBounds :169-195).  Pure
+ * host arithmetic; writes center[3] and *radius. */
+int32_t rtmi_bounding_sphere(const rtmi_triangle* triangles, int64_t n, double center[3],
+                             double* radius);
+
+/* Flatten and upload a scene to `device` (what the reference holds as the `objects`,
+ * `lights` arrays and material values at ViewController.swift:155-167).  The descriptor
+ * and everything it points to may be freed after the call returns. */
+int32_t rtmi_scene_create(const rtmi_scene_desc* desc, int32_t device, rtmi_scene** out);
+
+void rtmi_scene_destroy(rtmi_scene* scene);
+
+/* raytraceWorld (RayTracingFunctions.swift:145-180) into caller-owned HOST buffers.
+ *   rgba_out    4*width*height bytes, row-major RGBA8, bytesPerRow = 4*width
+ *               (RayTracingFunctions.swift:67,106-111); only rendered pixels are written.
+ *   hit_id_out  optional; width*height*spp int32, index (y*width + x)*spp + k with k in
+ *               WorldCoordinateSequence sample order (:74-78).  Values: triangle index
+ *               into triangles[] for a triangle hit, -2 - object_index for a sphere,
+ *               bounding-sphere-as-sphere or light hit, -1 for a miss.  Unrendered
+ *               samples are not written.
+ *   counters    optional.
+ * Synchronous. */
+int32_t rtmi_render(rtmi_scene* scene, const rtmi_camera* camera, const rtmi_params* params,
+                    uint8_t* rgba_out, int32_t* hit_id_out, rtmi_counters* counters);
+
+/* Same, but rgba_dev / hit_id_dev are DEVICE pointers on the scene's device (e.g. a torch
+ * tensor's data_ptr()).  All work is enqueued on an internal stream and the call returns
+ * after that stream has drained. */
+int32_t rtmi_render_device(rtmi_scene* scene, const rtmi_camera* camera,
+                           const rtmi_params* params, void* rgba_dev, void* hit_id_dev,
+                           rtmi_counters* counters);
+
+/* Number of sub-samples per pixel for a subdivision value: the count of
+ * stride(from: x, to: x+1, by: s) squared (WorldCoordinateSequence.swift:74-78). */
+int32_t rtmi_samples_per_pixel(double pixel_subdivision);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTMI_H */

@@ -1,0 +1,125 @@
+"""raytracer_amd -- MI355X (gfx950) render core for nealsid/RayTracer scenes.
+
+Python is harness only: the product is `librtmi.so` (HIP kernels + the C ABI declared in
+include/rtmi.h).  This module binds that ABI with ctypes.  There is no CPU fallback: if the
+shared library is missing or no gfx950 device is present, calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _abi, scenes  # noqa: F401
+from ._abi import Camera, Counters, Params, SceneDesc  # noqa: F401
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librtmi.so")
+_lib = None
+
+
+class RtmiError(RuntimeError):
+    def __init__(self, status, where, detail=""):
+        self.status = status
+        super().__init__(f"{where}: status {status}" + (f" ({detail})" if detail else ""))
+
+
+def lib():
+    """The loaded librtmi.so with argtypes set; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `make -C raytracer_amd/csrc` "
+                "(or __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.rtmi_abi_version.restype = C.c_int32
+        L.rtmi_status_string.restype = C.c_char_p
+        L.rtmi_status_string.argtypes = [C.c_int32]
+        L.rtmi_last_error.restype = C.c_char_p
+        L.rtmi_device_count.restype = C.c_int32
+        L.rtmi_samples_per_pixel.restype = C.c_int32
+        L.rtmi_samples_per_pixel.argtypes = [C.c_double]
+        L.rtmi_bounding_sphere.restype = C.c_int32
+        L.rtmi_bounding_sphere.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_double),
+                                           C.POINTER(C.c_double)]
+        L.rtmi_scene_create.restype = C.c_int32
+        L.rtmi_scene_create.argtypes = [C.POINTER(SceneDesc), C.c_int32, C.POINTER(C.c_void_p)]
+        L.rtmi_scene_destroy.restype = None
+        L.rtmi_scene_destroy.argtypes = [C.c_void_p]
+        L.rtmi_render.restype = C.c_int32
+        L.rtmi_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Params), C.c_void_p,
+                                  C.c_void_p, C.POINTER(Counters)]
+        L.rtmi_render_device.restype = C.c_int32
+        L.rtmi_render_device.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Params),
+                                         C.c_void_p, C.c_void_p, C.POINTER(Counters)]
+        if L.rtmi_abi_version() != _abi.RTMI_ABI_VERSION:
+            raise ImportError("librtmi.so ABI version does not match raytracer_amd/_abi.py")
+        _lib = L
+    return _lib
+
+
+def _check(rc, where):
+    if rc != 0:
+        L = lib()
+        detail = L.rtmi_status_string(rc).decode()
+        last = L.rtmi_last_error().decode()
+        raise RtmiError(rc, where, detail + (": " + last if last else ""))
+
+
+def samples_per_pixel(subdivision: float) -> int:
+    n = lib().rtmi_samples_per_pixel(float(subdivision))
+    _check(min(n, 0), "rtmi_samples_per_pixel")
+    return n
+
+
+def bounding_sphere(triangles: np.ndarray):
+    """Sphere(boundingObjects:) (Renderables.swift:215-246) -> (center tuple, radius)."""
+    c, r = (C.c_double * 3)(), C.c_double()
+    tri = np.ascontiguousarray(triangles)
+    _check(lib().rtmi_bounding_sphere(tri.ctypes.data, len(tri), c, C.byref(r)), "rtmi_bounding_sphere")
+    return tuple(c), r.value
+
+
+class Scene:
+    """A scene resident on one GPU (rtmi_scene_create / rtmi_scene_destroy)."""
+
+    def __init__(self, data: "scenes.SceneData", device: int = 0):
+        self._h = C.c_void_p()
+        self.data = data
+        self.device = device
+        desc = data.desc()
+        _check(lib().rtmi_scene_create(C.byref(desc), device, C.byref(self._h)), "rtmi_scene_create")
+
+    def close(self):
+        if self._h:
+            lib().rtmi_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render(self, camera: Camera, params: Params, want_hit_ids=True, rgba=None):
+        """raytraceWorld into host arrays.  Returns (rgba [H,W,4] u8, hit_id [H,W,spp] i32|None,
+        counters dict)."""
+        W, H = params.width, params.height
+        spp = samples_per_pixel(params.pixel_subdivision)
+        if rgba is None:
+            rgba = np.zeros((H, W, 4), np.uint8)
+        assert rgba.shape == (H, W, 4) and rgba.dtype == np.uint8 and rgba.flags["C_CONTIGUOUS"]
+        hit = np.full((H, W, spp), -1, np.int32) if want_hit_ids else None
+        cnt = Counters()
+        rc = lib().rtmi_render(self._h, C.byref(camera), C.byref(params), rgba.ctypes.data,
+                               hit.ctypes.data if want_hit_ids else None, C.byref(cnt))
+        _check(rc, "rtmi_render")
+        return rgba, hit, cnt.as_dict()
+
+    def render_device(self, camera: Camera, params: Params, rgba_ptr: int, hit_ptr: int = 0):
+        """raytraceWorld into device buffers (raw pointers).  Returns the counters dict."""
+        cnt = Counters()
+        rc = lib().rtmi_render_device(self._h, C.byref(camera), C.byref(params), C.c_void_p(rgba_ptr),
+                                      C.c_void_p(hit_ptr) if hit_ptr else None, C.byref(cnt))
+        _check(rc, "rtmi_render_device")
+        return cnt.as_dict()

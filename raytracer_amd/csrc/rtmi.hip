@@ -1,0 +1,1205 @@
+// rtmi.hip -- gfx950 (MI355X) kernels and the C ABI of include/rtmi.h.
+//
+// Replaces the reference's raytraceWorld / raytracePixels / calculateLighting call tree
+// (RayTraceUI/RayTracingFunctions.swift:59-114, :145-271) with a staged GPU pipeline:
+//
+//   k_pack_primary   per frame: triangles -> FP32 filter operands relative to the camera
+//   k_gen            per sample: ray generation + top-level sphere/light tests
+//   k_search_primary per (ray, triangle): packed-FP32 conservative filter, FP64 exact
+//                    re-test of every nominee; lowest list position wins
+//   k_shade          per hit sample: calculateLighting in FP64
+//   k_resolve        per pixel: sample average, x255 truncation, RGBA8 store
+//
+// The hot kernel is k_search_primary.  One lane owns R rays; triangle operands are
+// wave-uniform and arrive through scalar loads into SGPRs, two triangles per
+// v_pk_fma_f32; no LDS, no MFMA, no cross-lane traffic in the steady state.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see Makefile).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/rtmi.h"
+#include "rtmi_exact.h"
+
+using rtx::d3;
+using rtx::TriPlane;
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// ---------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+#define HIP_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      g_last_error = std::string(#expr) + ": " + hipGetErrorString(e_) + " (" + __FILE__ + \
+                     ":" + std::to_string(__LINE__) + ")";                                 \
+      return e_ == hipErrorOutOfMemory ? RTMI_ERR_OUT_OF_MEMORY : RTMI_ERR_HIP;            \
+    }                                                                                      \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------
+// device-side constants and helpers
+// ---------------------------------------------------------------------------------------
+constexpr int BLK = 8;              // pixel block edge; samples are enumerated block by block
+constexpr int BLK_PIX = BLK * BLK;  // so that 64 consecutive samples are screen neighbours
+constexpr int TRI_BATCH = 4;        // triangles per scalar-load batch of the filter loop
+constexpr int FILT_FLOATS = 9 * TRI_BATCH;  // 3 edge planes x 3 components per triangle
+
+struct FrameConst {
+  double ul[3], u[3], v[3], cam[3];
+  double ppw_h, ppw_v, sub;
+  double ambient[3];
+  int W, H, x0, y0, x1, y1;
+  int spp, n1;  // samples per pixel = n1*n1 (WorldCoordinateSequence.swift:74-78)
+  int tile_size, tiles_x, tile_rank, tile_world;
+};
+
+struct DevCounters {
+  unsigned long long samples, rays_reflection, rays_shadow, tri_tests, sphere_tests,
+      tri_exact_tests, primary_hits, tri_tests_primary_kernel;
+  int q_child, q_shade, q_top;  // queue fill levels
+  int pad;
+};
+
+struct SceneDev {
+  const rtmi_object* objects;
+  const rtmi_light* lights;
+  const rtmi_material* materials;
+  const rtmi_triangle* tris;
+  const TriPlane* planes;
+  int n_objects, n_lights, n_sphere_like;
+  long long n_top_tris;
+};
+
+// sample index within a batch -> pixel and sub-sample; false if the pixel is not rendered
+__device__ inline bool sample_coords(const FrameConst& fc, const int2* __restrict__ blocks, int s,
+                                     int* x, int* y, int* k) {
+  int per_block = BLK_PIX * fc.spp;
+  int b = s / per_block;
+  int rem = s - b * per_block;
+  int pix = rem / fc.spp;
+  *k = rem - pix * fc.spp;
+  int2 bc = blocks[b];
+  int px = bc.x * BLK + (pix & (BLK - 1));
+  int py = bc.y * BLK + (pix >> 3);
+  *x = px;
+  *y = py;
+  if (px < fc.x0 || px >= fc.x1 || py < fc.y0 || py >= fc.y1) return false;
+  if (fc.tile_size > 0 && fc.tile_world > 1) {
+    int tile = (py / fc.tile_size) * fc.tiles_x + (px / fc.tile_size);
+    if (tile % fc.tile_world != fc.tile_rank) return false;
+  }
+  return true;
+}
+
+// Primary ray direction of sample k of pixel (x, y): WorldCoordinateSequence.swift:62-78 and
+// RayTracingFunctions.swift:73.
+__device__ inline d3 sample_dir(const FrameConst& fc, int x, int y, int k) {
+  int kx = k / fc.n1, ky = k - kx * fc.n1;  // x outer, y inner
+  double i = fma((double)kx, fc.sub, (double)x);  // stride(from:to:by:) = start.addingProduct(k, by)
+  double j = fma((double)ky, fc.sub, (double)y);
+  d3 p = rtx::pixel_to_world(rtx::ld3(fc.ul), rtx::ld3(fc.u), rtx::ld3(fc.v), fc.ppw_h, fc.ppw_v, i, j);
+  return rtx::normalize(rtx::sub(p, rtx::ld3(fc.cam)));
+}
+
+__device__ inline void wave_append(int* counter, int* queue, bool pred, int value) {
+  unsigned long long mask = __ballot(pred);
+  if (mask == 0) return;
+  int lane = threadIdx.x & 63;
+  int leader = __ffsll((long long)mask) - 1;
+  int base = 0;
+  if (lane == leader) base = atomicAdd(counter, __popcll(mask));
+  base = __shfl(base, leader);
+  if (pred) queue[base + __popcll(mask & ((1ull << lane) - 1ull))] = value;
+}
+
+__device__ inline void wave_count(unsigned long long* counter, unsigned long long v) {
+  // sum v over the active lanes, one atomic per wave
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+  if ((threadIdx.x & 63) == 0 && v) atomicAdd(counter, v);
+}
+
+// ---------------------------------------------------------------------------------------
+// scene preparation
+// ---------------------------------------------------------------------------------------
+__global__ void k_tri_planes(const rtmi_triangle* __restrict__ tris, long long n, TriPlane* planes) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const rtmi_triangle& t = tris[i];
+  planes[i] = rtx::tri_plane(rtx::ld3(t.v[0]), rtx::ld3(t.v[1]), rtx::ld3(t.v[2]));
+}
+
+// Per frame, per triangle group: decide which triangles a ray from `cam` can hit at all
+// (the reference's `t > 0`, Renderables.swift:150-152, is ray-independent for a common
+// origin: t = num / -nddot with -nddot < 0, so t > 0 iff num < 0) and count them per block.
+__global__ void k_pack_flags(const rtmi_triangle* __restrict__ tris, const TriPlane* __restrict__ planes,
+                             const int* __restrict__ group, int n, d3 cam, unsigned char* keep,
+                             int* block_counts) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool k = false;
+  if (i < n) {
+    const TriPlane pl = planes[group[i]];
+    double num = pl.c - rtx::dp(rtx::mk(pl.nx, pl.ny, pl.nz), cam);
+    k = num < 0;  // false for NaN (degenerate triangle): never hit in the reference either
+    keep[i] = k;
+  }
+  unsigned long long m = __ballot(k);
+  __shared__ int wsum[4];
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = __popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// exclusive scan of the per-block counts, one workgroup
+__global__ void k_pack_scan(int* block_counts, int nblocks, int* npacked_out) {
+  __shared__ int part[1024];
+  int t = threadIdx.x;
+  int per = (nblocks + 1023) / 1024;
+  int lo = t * per, hi = min(lo + per, nblocks);
+  int s = 0;
+  for (int i = lo; i < hi; ++i) s += block_counts[i];
+  part[t] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    int v = t >= off ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = part[t] - s;
+  for (int i = lo; i < hi; ++i) {
+    int c = block_counts[i];
+    block_counts[i] = run;
+    run += c;
+  }
+  if (t == 1023) *npacked_out = part[1023];
+}
+
+// Write the filter operands of every kept triangle at its compacted position.
+//
+// For a ray from the common origin o with unit direction d, the reference's three inside
+// tests (Renderables.swift:158-163) are equivalent, given n.d < 0, to d.M_i <= 0 with
+// M_0 = (v0-o)x(v1-o), M_1 = (v1-o)x(v2-o), M_2 = (v2-o)x(v0-o): for the plane point P,
+// e01 x (P - v0) = lambda*n and d.(e01 x (P - v0)) = d.((v0-o)x(v1-o)).  The filter
+// evaluates s_i = d.M_i/E_i in FP32 and nominates the pair when max_i s_i <= 1, where
+// E_i = 16*2^-24*|M_i|_1 + 2^-40*L^2 bounds the FP32 evaluation error (operand roundings,
+// one product and two fma roundings: < 8*2^-24*|M_i|_1 for |d_k| <= 1) plus the rounding
+// of the reference's own FP64 formulas (about 2^-46*L^2, L = |o|_1 + max|v|_1).  Every
+// pair the reference accepts is therefore nominated; nominees are re-decided in FP64.
+__global__ void k_pack_write(const rtmi_triangle* __restrict__ tris, const int* __restrict__ group, int n,
+                             d3 cam, const unsigned char* __restrict__ keep,
+                             const int* __restrict__ block_offsets, float* filt, int* packed_tri) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool k = i < n && keep[i];
+  unsigned long long m = __ballot(k);
+  __shared__ int wsum[4];
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) wsum[w] = __popcll(m);
+  __syncthreads();
+  if (!k) return;
+  int pos = block_offsets[blockIdx.x] + __popcll(m & ((1ull << lane) - 1ull));
+  for (int q = 0; q < w; ++q) pos += wsum[q];
+
+  int ti = group[i];
+  const rtmi_triangle& t = tris[ti];
+  d3 A = rtx::sub(rtx::ld3(t.v[0]), cam), B = rtx::sub(rtx::ld3(t.v[1]), cam), Cc = rtx::sub(rtx::ld3(t.v[2]), cam);
+  d3 M[3] = {rtx::cross(A, B), rtx::cross(B, Cc), rtx::cross(Cc, A)};
+  double L = fabs(cam.x) + fabs(cam.y) + fabs(cam.z);
+  double lv = 0;
+  for (int q = 0; q < 3; ++q) lv = fmax(lv, fabs(t.v[q][0]) + fabs(t.v[q][1]) + fabs(t.v[q][2]));
+  L += lv;
+  const double eps32 = 5.9604644775390625e-08;     // 2^-24
+  const double abs_term = 9.094947017729282e-13;   // 2^-40
+  int b = pos / TRI_BATCH, j = pos % TRI_BATCH;
+  float* dst = filt + (size_t)b * FILT_FLOATS + (j >> 1) * 18 + (j & 1);
+  for (int e = 0; e < 3; ++e) {
+    double E = 16.0 * eps32 * (fabs(M[e].x) + fabs(M[e].y) + fabs(M[e].z)) + abs_term * L * L;
+    float mx = (float)(M[e].x / E), my = (float)(M[e].y / E), mz = (float)(M[e].z / E);
+    if (!(E > 0) || !isfinite(mx) || !isfinite(my) || !isfinite(mz)) mx = my = mz = 0.0f;  // always nominate
+    dst[(e * 3 + 0) * 2] = mx;
+    dst[(e * 3 + 1) * 2] = my;
+    dst[(e * 3 + 2) * 2] = mz;
+  }
+  packed_tri[pos] = ti;
+}
+
+// ---------------------------------------------------------------------------------------
+// top-level tests against spheres, bounding spheres and lights (FP64, list order)
+// ---------------------------------------------------------------------------------------
+struct Hit {
+  d3 P, n;
+  double t;
+  int has_normal;
+  int material;
+  int id;  // triangle index, or -2 - object index
+};
+
+// intersections[0] over the sphere-like members of the top-level list, skipping triangle
+// runs (they are searched separately).  Returns the object index or -1.
+__device__ inline int first_sphere_like(const SceneDev& sc, d3 o, d3 d, Hit* h) {
+  for (int k = 0; k < sc.n_objects; ++k) {
+    const rtmi_object& ob = sc.objects[k];
+    if (ob.kind == RTMI_SPHERE || ob.kind == RTMI_BOUNDING_SPHERE) {
+      double t;
+      d3 P, n;
+      if (rtx::sphere_first(rtx::ld3(ob.center), ob.radius, o, d, &t, &P, &n)) {
+        h->P = P; h->n = n; h->t = t; h->has_normal = 1; h->material = ob.material; h->id = -2 - k;
+        return k;
+      }
+    } else if (ob.kind == RTMI_LIGHT) {
+      double t;
+      d3 P;
+      if (rtx::light_hit(rtx::ld3(sc.lights[ob.first].loc), o, d, &t, &P)) {
+        h->P = P; h->t = t; h->has_normal = 0; h->material = -1; h->id = -2 - k;
+        return k;
+      }
+    }
+  }
+  return -1;
+}
+
+// FP64 scan of a triangle index range for the first hit in order (reference order).  Used
+// for secondary rays against top-level triangle runs.
+__device__ inline long long first_tri_exact(const SceneDev& sc, long long first, long long count, d3 o, d3 d,
+                                            double* t, d3* P) {
+  for (long long i = first; i < first + count; ++i) {
+    const rtmi_triangle& tr = sc.tris[i];
+    if (rtx::tri_hit(rtx::ld3(tr.v[0]), rtx::ld3(tr.v[1]), rtx::ld3(tr.v[2]), sc.planes[i], o, d, t, P)) return i;
+  }
+  return -1;
+}
+
+// traceRay over the whole top-level list (RayTracingFunctions.swift:37-44) for a secondary
+// ray: intersections[0] if want_first, and whether any non-bounding object is hit.
+__device__ inline bool trace_top_secondary(const SceneDev& sc, d3 o, d3 d, bool want_first, Hit* h,
+                                           bool* any_non_bounding) {
+  bool found = false, anb = false;
+  for (int k = 0; k < sc.n_objects; ++k) {
+    if (want_first ? found : anb) break;
+    const rtmi_object& ob = sc.objects[k];
+    if (ob.kind == RTMI_SPHERE || ob.kind == RTMI_BOUNDING_SPHERE) {
+      double t;
+      d3 P, n;
+      if (want_first && !found) {
+        if (rtx::sphere_first(rtx::ld3(ob.center), ob.radius, o, d, &t, &P, &n)) {
+          found = true;
+          if (ob.kind == RTMI_SPHERE) anb = true;
+          h->P = P; h->n = n; h->t = t; h->has_normal = 1; h->material = ob.material; h->id = -2 - k;
+        }
+      } else if (ob.kind == RTMI_SPHERE) {
+        if (rtx::sphere_any(rtx::ld3(ob.center), ob.radius, o, d)) anb = true;
+      }
+    } else if (ob.kind == RTMI_TRIANGLES) {
+      double t;
+      d3 P;
+      long long i = first_tri_exact(sc, ob.first, ob.count, o, d, &t, &P);
+      if (i >= 0) {
+        anb = true;
+        if (!found) {
+          found = true;
+          const TriPlane pl = sc.planes[i];
+          h->P = P; h->n = rtx::mk(pl.nx, pl.ny, pl.nz); h->t = t; h->has_normal = 1;
+          h->material = sc.tris[i].material; h->id = (int)i;
+        }
+      }
+    } else if (ob.kind == RTMI_LIGHT) {
+      double t;
+      d3 P;
+      if (rtx::light_hit(rtx::ld3(sc.lights[ob.first].loc), o, d, &t, &P)) {
+        anb = true;
+        if (!found) {
+          found = true;
+          h->P = P; h->t = t; h->has_normal = 0; h->material = -1; h->id = -2 - k;
+        }
+      }
+    }
+  }
+  *any_non_bounding = anb;
+  return found;
+}
+
+// ---------------------------------------------------------------------------------------
+// k_gen: one thread per sample of the batch
+// ---------------------------------------------------------------------------------------
+// Outcome per sample (hit_id): -1 miss / unrendered; >= 0 triangle; <= -2 sphere-like object.
+// With no top-level triangle runs the sample is resolved here: a sphere or light hit goes to
+// the shade queue, a bounding-sphere hit to the child-search queue.  With top-level runs
+// every rendered sample goes on to the top-level triangle search, which resolves it.
+__global__ void __launch_bounds__(256)
+k_gen(FrameConst fc, SceneDev sc, const int2* __restrict__ blocks, int nsamples, int* hit_id, int* q_child,
+      int* q_shade, int* q_top, DevCounters* cnt) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  int x, y, k;
+  bool live = s < nsamples && sample_coords(fc, blocks, s, &x, &y, &k);
+  int id = -1;
+  bool to_child = false, to_shade = false;
+  if (live) {
+    d3 d = sample_dir(fc, x, y, k);
+    Hit h;
+    int obj = first_sphere_like(sc, rtx::ld3(fc.cam), d, &h);
+    if (obj >= 0) {
+      id = -2 - obj;
+      if (sc.objects[obj].kind == RTMI_BOUNDING_SPHERE) to_child = true; else to_shade = true;
+    }
+  }
+  if (s < nsamples) hit_id[s] = live ? id : -1;
+  if (sc.n_top_tris > 0) {
+    // resolved after the top-level triangle search (k_resolve_top)
+    wave_append(&cnt->q_top, q_top, live, s);
+  } else {
+    wave_append(&cnt->q_child, q_child, to_child, s);
+    wave_append(&cnt->q_shade, q_shade, to_shade, s);
+  }
+  wave_count(&cnt->samples, live ? 1ull : 0ull);
+  wave_count(&cnt->sphere_tests, live ? (unsigned long long)sc.n_sphere_like : 0ull);
+}
+
+// After the top-level triangle search: combine the first sphere-like object (hit_id from
+// k_gen) with the first top-level triangle (tri_hit) by list position.
+__global__ void __launch_bounds__(256)
+k_resolve_top(SceneDev sc, const int* __restrict__ q_top, const int* __restrict__ nq_ptr, const int* __restrict__ tri_hit,
+              const int* __restrict__ tri_owner, int* hit_id, int* q_child, int* q_shade, DevCounters* cnt) {
+  int q = blockIdx.x * blockDim.x + threadIdx.x;
+  bool to_child = false, to_shade = false;
+  int s = -1;
+  if (q < *nq_ptr) {
+    s = q_top[q];
+    int id = hit_id[s];
+    int th = tri_hit[q];
+    int obj = id <= -2 ? -2 - id : 0x7fffffff;
+    if (th >= 0 && tri_owner[th] < obj) { id = th; obj = -1; }
+    hit_id[s] = id;
+    if (id >= 0) to_shade = true;
+    else if (id <= -2) {
+      if (sc.objects[obj].kind == RTMI_BOUNDING_SPHERE) to_child = true; else to_shade = true;
+    }
+  }
+  wave_append(&cnt->q_child, q_child, to_child, s);
+  wave_append(&cnt->q_shade, q_shade, to_shade, s);
+}
+
+// ---------------------------------------------------------------------------------------
+// k_search_primary: the hot kernel
+// ---------------------------------------------------------------------------------------
+// Each lane owns R rays (queue entries base + r*64 + lane) that share the camera origin.
+// Triangles arrive four at a time as 18 float2 = 9 x (tri a, tri b) + 9 x (tri c, tri d),
+// wave-uniform, so the compiler keeps them in SGPRs (s_load_dwordx16) and feeds them to
+// v_pk_mul_f32 / v_pk_fma_f32 as the scalar operand; the next batch is loaded while the
+// current one is evaluated.  Per (ray, triangle): 4.5 packed FMA-class instructions,
+// one v_max3_f32 and half a v_min3_f32.  A lane whose running minimum drops to <= 1 takes
+// the rare path: find the nominee(s), re-test each in FP64 in list order, keep the first
+// hit, and poison the ray direction with NaN so that ray nominates nothing afterwards.
+// The wave leaves the loop once every one of its rays has a hit.
+//
+// mode 0: queue entries are sample ids awaiting the children of bounding object
+//         `obj_filter`; the result is written to hit_id[s] and hits are appended to q_shade.
+// mode 1: top-level runs; the result (triangle index or -1) goes to tri_hit[q].
+template <int R>
+__global__ void __launch_bounds__(256)
+k_search_primary(FrameConst fc, SceneDev sc, const int2* __restrict__ blocks, const int* __restrict__ queue,
+                 const int* __restrict__ nq_ptr, int mode, int obj_filter, const f2* __restrict__ filt,
+                 const int* __restrict__ npacked_ptr, const int* __restrict__ packed_tri, int* hit_id,
+                 int* tri_hit, int* q_shade, DevCounters* cnt) {
+  const int nq = *nq_ptr;
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int base = wave * 64 * R;
+  if (base >= nq) return;
+  const int npacked = *npacked_ptr;
+  const int nbatch = (npacked + TRI_BATCH - 1) / TRI_BATCH;
+
+  int sid[R], best[R], upto[R];
+  bool valid[R];
+  float dx[R], dy[R], dz[R];
+  const float qnan = __builtin_nanf("");
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    int q = base + r * 64 + lane;
+    valid[r] = q < nq;
+    sid[r] = valid[r] ? queue[q] : -1;
+    best[r] = -1;
+    upto[r] = 0;
+    if (valid[r] && mode == 0 && hit_id[sid[r]] != -2 - obj_filter) valid[r] = false;
+    dx[r] = dy[r] = dz[r] = qnan;
+    if (valid[r]) {
+      int x, y, k;
+      sample_coords(fc, blocks, sid[r], &x, &y, &k);
+      d3 d = sample_dir(fc, x, y, k);
+      dx[r] = (float)d.x; dy[r] = (float)d.y; dz[r] = (float)d.z;
+    }
+  }
+
+  int done_batches = nbatch;
+  if (nbatch > 0) {
+    f2 cur[18];
+#pragma unroll
+    for (int c = 0; c < 18; ++c) cur[c] = filt[c];
+    for (int b = 0; b < nbatch; ++b) {
+      f2 nxt[18];
+      const f2* p = filt + (size_t)(b + 1) * 18;  // one spare batch is allocated past the end
+#pragma unroll
+      for (int c = 0; c < 18; ++c) nxt[c] = p[c];
+
+      float mn = 3.0e38f;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          f2 X = {dx[r], dx[r]}, Y = {dy[r], dy[r]}, Z = {dz[r], dz[r]};
+          f2 s0 = __builtin_elementwise_fma(cur[h * 9 + 2], Z, __builtin_elementwise_fma(cur[h * 9 + 1], Y, cur[h * 9 + 0] * X));
+          f2 s1 = __builtin_elementwise_fma(cur[h * 9 + 5], Z, __builtin_elementwise_fma(cur[h * 9 + 4], Y, cur[h * 9 + 3] * X));
+          f2 s2 = __builtin_elementwise_fma(cur[h * 9 + 8], Z, __builtin_elementwise_fma(cur[h * 9 + 7], Y, cur[h * 9 + 6] * X));
+          float ma = __builtin_fmaxf(__builtin_fmaxf(s0.x, s1.x), s2.x);
+          float mb = __builtin_fmaxf(__builtin_fmaxf(s0.y, s1.y), s2.y);
+          mn = __builtin_fminf(__builtin_fminf(mn, ma), mb);
+        }
+      }
+
+      if (__builtin_expect(__any(mn <= 1.0f), 0)) {
+        if (mn <= 1.0f) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            if (best[r] >= 0 || !valid[r]) continue;
+#pragma unroll
+            for (int j = 0; j < TRI_BATCH; ++j) {
+              if (best[r] >= 0) continue;
+              const int h = j >> 1;
+              float m[9];
+#pragma unroll
+              for (int c = 0; c < 9; ++c) m[c] = (j & 1) ? cur[h * 9 + c].y : cur[h * 9 + c].x;
+              float s0 = __builtin_fmaf(m[2], dz[r], __builtin_fmaf(m[1], dy[r], m[0] * dx[r]));
+              float s1 = __builtin_fmaf(m[5], dz[r], __builtin_fmaf(m[4], dy[r], m[3] * dx[r]));
+              float s2 = __builtin_fmaf(m[8], dz[r], __builtin_fmaf(m[7], dy[r], m[6] * dx[r]));
+              float mx = __builtin_fmaxf(__builtin_fmaxf(s0, s1), s2);
+              if (mx <= 1.0f) {
+                int g = b * TRI_BATCH + j;
+                if (g < npacked) {
+                  int ti = packed_tri[g];
+                  int x, y, k;
+                  sample_coords(fc, blocks, sid[r], &x, &y, &k);
+                  d3 d = sample_dir(fc, x, y, k);
+                  const rtmi_triangle& tr = sc.tris[ti];
+                  double t;
+                  d3 P;
+                  atomicAdd(&cnt->tri_exact_tests, 1ull);
+                  if (rtx::tri_hit(rtx::ld3(tr.v[0]), rtx::ld3(tr.v[1]), rtx::ld3(tr.v[2]), sc.planes[ti],
+                                   rtx::ld3(fc.cam), d, &t, &P)) {
+                    best[r] = ti;
+                    upto[r] = g + 1;  // list positions this ray consumed
+                    dx[r] = dy[r] = dz[r] = qnan;
+                  }
+                }
+              }
+            }
+          }
+        }
+        bool all_done = true;
+#pragma unroll
+        for (int r = 0; r < R; ++r) all_done = all_done && (best[r] >= 0 || !valid[r]);
+        if (__all(all_done)) { done_batches = b + 1; break; }
+      }
+#pragma unroll
+      for (int c = 0; c < 18; ++c) cur[c] = nxt[c];
+    }
+  }
+
+  // a ray with a hit consumed the list up to that hit; a ray without one consumed every
+  // packed triangle the wave walked
+  unsigned long long walked = (unsigned long long)min(done_batches * TRI_BATCH, npacked);
+  unsigned long long tests = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (valid[r]) tests += best[r] >= 0 ? (unsigned long long)upto[r] : walked;
+  }
+  wave_count(&cnt->tri_tests_primary_kernel, tests);
+
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    int q = base + r * 64 + lane;
+    if (mode == 0) {
+      if (valid[r]) hit_id[sid[r]] = best[r];
+      wave_append(&cnt->q_shade, q_shade, valid[r] && best[r] >= 0, sid[r]);
+    } else {
+      if (q < nq) tri_hit[q] = best[r];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_shade: calculateLighting (RayTracingFunctions.swift:182-271) for every hit sample
+// ---------------------------------------------------------------------------------------
+struct RGBd {
+  double r, g, b;
+};
+
+template <bool REFLECT>
+__device__ RGBd calculate_lighting(const SceneDev& sc, const FrameConst& fc, const Hit& is, d3 camera,
+                                   unsigned long long* n_refl, unsigned long long* n_shadow) {
+  d3 surface_point = is.P;
+  RGBd I = {0.0, 0.0, 0.0};
+  const bool has_material = is.material >= 0;
+  rtmi_material mat;
+  if (has_material) {
+    mat = sc.materials[is.material];
+    // intensityMultiplier = ambientLight; intensityMultiplier.scale(material.ambient)  RTF:193-196
+    I.r = mat.Ka[0] * fc.ambient[0];
+    I.g = mat.Ka[1] * fc.ambient[1];
+    I.b = mat.Ka[2] * fc.ambient[2];
+  }
+  if (!is.has_normal) return I;  // RTF:199-202
+  d3 normal = is.n;
+  d3 surface_to_camera = rtx::normalize(rtx::sub(camera, surface_point));  // RTF:204
+
+  if constexpr (REFLECT) {  // RTF:207-224
+    d3 incident = rtx::neg(surface_to_camera);
+    d3 reflection = rtx::sub(incident, rtx::smul(2 * rtx::dp(incident, normal), normal));
+    RGBd contribution = {0.0, 0.0, 0.0};
+    Hit rh;
+    bool anb;
+    *n_refl += 1;
+    if (trace_top_secondary(sc, surface_point, reflection, true, &rh, &anb)) {
+      contribution = calculate_lighting<false>(sc, fc, rh, surface_point, n_refl, n_shadow);
+    }
+    I.r = I.r + contribution.r;
+    I.g = I.g + contribution.g;
+    I.b = I.b + contribution.b;
+  }
+
+  for (int li = 0; li < sc.n_lights; ++li) {  // RTF:226-268
+    const rtmi_light& light = sc.lights[li];
+    d3 point_to_light = rtx::normalize(rtx::sub(rtx::ld3(light.loc), surface_point));
+    double ndl = rtx::dp(point_to_light, normal);
+    if (ndl <= 0) continue;
+    Hit dummy;
+    bool anb = false;
+    *n_shadow += 1;
+    trace_top_secondary(sc, surface_point, point_to_light, false, &dummy, &anb);
+    if (anb) continue;           // RTF:241
+    if (!has_material) continue; // RTF:245
+    double lr = light.diffuse[0], lg = light.diffuse[1], lb = light.diffuse[2];
+    lr = ndl * lr; lg = ndl * lg; lb = ndl * lb;                    // scale(normalLightVectorDp)
+    lr = mat.Kd[0] * lr; lg = mat.Kd[1] * lg; lb = mat.Kd[2] * lb;  // scale(material.diffuse)
+    I.r = I.r + lr; I.g = I.g + lg; I.b = I.b + lb;
+    d3 light_reflection = rtx::normalize(rtx::sub(rtx::smul(2 * ndl, normal), point_to_light));  // RTF:251
+    double rv = rtx::dp(light_reflection, surface_to_camera);
+    if (rv <= 0) continue;  // RTF:255-257
+    double specular_term = pow(rv, mat.Ns);  // RTF:259
+    double sr = light.specular[0], sg = light.specular[1], sb = light.specular[2];
+    sr = specular_term * sr; sg = specular_term * sg; sb = specular_term * sb;
+    sr = mat.Ks[0] * sr; sg = mat.Ks[1] * sg; sb = mat.Ks[2] * sb;
+    sr = rtx::clamp01(sr); sg = rtx::clamp01(sg); sb = rtx::clamp01(sb);  // RTF:263
+    I.r = I.r + sr; I.g = I.g + sg; I.b = I.b + sb;
+  }
+  I.r = rtx::clamp01(I.r); I.g = rtx::clamp01(I.g); I.b = rtx::clamp01(I.b);  // RTF:269
+  return I;
+}
+
+__global__ void __launch_bounds__(256)
+k_shade(FrameConst fc, SceneDev sc, const int2* __restrict__ blocks, const int* __restrict__ q_shade,
+        const int* __restrict__ nq_ptr, const int* __restrict__ hit_id, double* rgb, DevCounters* cnt) {
+  int q = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long n_refl = 0, n_shadow = 0, n_hit = 0;
+  if (q < *nq_ptr) {
+    int s = q_shade[q];
+    int x, y, k;
+    sample_coords(fc, blocks, s, &x, &y, &k);
+    d3 d = sample_dir(fc, x, y, k);
+    d3 cam = rtx::ld3(fc.cam);
+    int id = hit_id[s];
+    Hit h;
+    bool ok = false;
+    if (id >= 0) {
+      const rtmi_triangle& tr = sc.tris[id];
+      const TriPlane pl = sc.planes[id];
+      ok = rtx::tri_hit(rtx::ld3(tr.v[0]), rtx::ld3(tr.v[1]), rtx::ld3(tr.v[2]), pl, cam, d, &h.t, &h.P);
+      h.n = rtx::mk(pl.nx, pl.ny, pl.nz);
+      h.has_normal = 1;
+      h.material = tr.material;
+      h.id = id;
+    } else {
+      const rtmi_object& ob = sc.objects[-2 - id];
+      if (ob.kind == RTMI_LIGHT) {
+        ok = rtx::light_hit(rtx::ld3(sc.lights[ob.first].loc), cam, d, &h.t, &h.P);
+        h.has_normal = 0;
+        h.material = -1;
+      } else {
+        ok = rtx::sphere_first(rtx::ld3(ob.center), ob.radius, cam, d, &h.t, &h.P, &h.n);
+        h.has_normal = 1;
+        h.material = ob.material;
+      }
+      h.id = id;
+    }
+    RGBd c = {0.0, 0.0, 0.0};
+    if (ok) {
+      n_hit = 1;
+      c = calculate_lighting<true>(sc, fc, h, cam, &n_refl, &n_shadow);
+    }
+    rgb[(size_t)s * 3 + 0] = c.r;
+    rgb[(size_t)s * 3 + 1] = c.g;
+    rgb[(size_t)s * 3 + 2] = c.b;
+  }
+  wave_count(&cnt->primary_hits, n_hit);
+  wave_count(&cnt->rays_reflection, n_refl);
+  wave_count(&cnt->rays_shadow, n_shadow);
+  // every secondary ray is tested against every top-level object by the reference
+  wave_count(&cnt->sphere_tests, (n_refl + n_shadow) * (unsigned long long)sc.n_sphere_like);
+  wave_count(&cnt->tri_tests, (n_refl + n_shadow) * (unsigned long long)sc.n_top_tris);
+}
+
+// ---------------------------------------------------------------------------------------
+// k_resolve: per pixel average and RGBA8 store (RayTracingFunctions.swift:105-111,
+// Utilities.swift:54-65)
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_resolve(FrameConst fc, const int2* __restrict__ blocks, int npix, const int* __restrict__ hit_id,
+          const double* __restrict__ rgb, unsigned char* rgba, int* hit_out) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npix) return;
+  int s0 = p * fc.spp;
+  int x, y, k;
+  if (!sample_coords(fc, blocks, s0, &x, &y, &k)) return;
+  double cr = 0.0, cg = 0.0, cb = 0.0;
+  for (int q = 0; q < fc.spp; ++q) {
+    int id = hit_id[s0 + q];
+    double r = 0.0, g = 0.0, b = 0.0;
+    if (id != -1) {
+      r = rgb[(size_t)(s0 + q) * 3 + 0];
+      g = rgb[(size_t)(s0 + q) * 3 + 1];
+      b = rgb[(size_t)(s0 + q) * 3 + 2];
+    }
+    cr = cr + r; cg = cg + g; cb = cb + b;
+    if (hit_out) hit_out[((size_t)y * fc.W + x) * fc.spp + q] = id;
+  }
+  double factor = 1 / (double)fc.spp;
+  double ar = factor * cr, ag = factor * cg, ab = factor * cb;
+  size_t first_byte = (size_t)4 * fc.W * y + (size_t)x * 4;
+  rgba[first_byte] = (unsigned char)(255 * ar);
+  rgba[first_byte + 1] = (unsigned char)(255 * ag);
+  rgba[first_byte + 2] = (unsigned char)(255 * ab);
+  rgba[first_byte + 3] = 255;
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+struct TriGroup {
+  int object;          // owning object index (bounding sphere), or -1 for the top-level runs
+  int n = 0;           // triangles in the group
+  int* d_group = nullptr;       // ordinal -> triangle index
+  unsigned char* d_keep = nullptr;
+  int* d_block_counts = nullptr;
+  float* d_filt = nullptr;      // (n/4 + 2) batches of FILT_FLOATS
+  int* d_packed_tri = nullptr;
+  int* d_npacked = nullptr;     // triangles kept by the last pack
+  size_t filt_bytes = 0;
+};
+
+struct rtmi_scene {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr;
+  std::vector<rtmi_object> objects;
+  int n_lights = 0, n_materials = 0;
+  long long n_tris = 0;
+  rtmi_object* d_objects = nullptr;
+  rtmi_light* d_lights = nullptr;
+  rtmi_material* d_materials = nullptr;
+  rtmi_triangle* d_tris = nullptr;
+  TriPlane* d_planes = nullptr;
+  int* d_tri_owner = nullptr;
+  std::vector<TriGroup> groups;  // [0] = top-level runs (may be empty), then bounding objects
+  SceneDev dev{};
+  // per-batch work buffers, grown on demand
+  size_t cap_samples = 0;
+  int* d_hit_id = nullptr;
+  int* d_tri_hit = nullptr;
+  int* d_q_child = nullptr;
+  int* d_q_shade = nullptr;
+  int* d_q_top = nullptr;
+  double* d_rgb = nullptr;
+  int2* d_blocks = nullptr;
+  size_t cap_blocks = 0;
+  DevCounters* d_cnt = nullptr;
+  std::mutex mu;
+};
+
+static int32_t validate_scene(const rtmi_scene_desc* s) {
+  if (!s) return RTMI_ERR_INVALID_ARGUMENT;
+  if (s->n_lights < 0 || s->n_materials < 0 || s->n_objects < 0 || s->n_triangles < 0) return RTMI_ERR_INVALID_ARGUMENT;
+  if ((s->n_lights && !s->lights) || (s->n_materials && !s->materials) || (s->n_objects && !s->objects) ||
+      (s->n_triangles && !s->triangles))
+    return RTMI_ERR_INVALID_ARGUMENT;
+  if (s->n_triangles > 0x7ffffff0LL || s->n_objects > 0x3fffffffLL) return RTMI_ERR_UNSUPPORTED;
+  for (int64_t k = 0; k < s->n_objects; ++k) {
+    const rtmi_object& ob = s->objects[k];
+    if (ob.material >= s->n_materials) return RTMI_ERR_INVALID_ARGUMENT;
+    switch (ob.kind) {
+      case RTMI_SPHERE: break;
+      case RTMI_TRIANGLES:
+      case RTMI_BOUNDING_SPHERE:
+        if (ob.first < 0 || ob.count < 0 || ob.first + ob.count > s->n_triangles) return RTMI_ERR_INVALID_ARGUMENT;
+        break;
+      case RTMI_LIGHT:
+        if (ob.first < 0 || ob.first >= s->n_lights) return RTMI_ERR_INVALID_ARGUMENT;
+        break;
+      default: return RTMI_ERR_INVALID_ARGUMENT;
+    }
+  }
+  for (int64_t i = 0; i < s->n_triangles; ++i)
+    if (s->triangles[i].material >= s->n_materials) return RTMI_ERR_INVALID_ARGUMENT;
+  return RTMI_OK;
+}
+
+static int32_t alloc_group(TriGroup& g, const std::vector<int>& idx) {
+  g.n = (int)idx.size();
+  if (g.n == 0) return RTMI_OK;
+  int nblocks = (g.n + 255) / 256;
+  HIP_TRY(hipMalloc(&g.d_group, sizeof(int) * g.n));
+  HIP_TRY(hipMemcpy(g.d_group, idx.data(), sizeof(int) * g.n, hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&g.d_keep, g.n));
+  HIP_TRY(hipMalloc(&g.d_block_counts, sizeof(int) * nblocks));
+  g.filt_bytes = sizeof(float) * FILT_FLOATS * ((size_t)(g.n + TRI_BATCH - 1) / TRI_BATCH + 2);
+  HIP_TRY(hipMalloc(&g.d_filt, g.filt_bytes));
+  HIP_TRY(hipMalloc(&g.d_packed_tri, sizeof(int) * g.n));
+  HIP_TRY(hipMalloc(&g.d_npacked, sizeof(int)));
+  HIP_TRY(hipMemset(g.d_npacked, 0, sizeof(int)));
+  return RTMI_OK;
+}
+
+extern "C" int32_t rtmi_abi_version(void) { return RTMI_ABI_VERSION; }
+
+extern "C" const char* rtmi_status_string(int32_t status) {
+  switch (status) {
+    case RTMI_OK: return "ok";
+    case RTMI_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case RTMI_ERR_UNSUPPORTED: return "unsupported input";
+    case RTMI_ERR_NO_DEVICE: return "no usable gfx950 device";
+    case RTMI_ERR_HIP: return "HIP runtime error";
+    case RTMI_ERR_OUT_OF_MEMORY: return "out of device memory";
+    default: return "unknown status";
+  }
+}
+
+extern "C" const char* rtmi_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int32_t rtmi_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    g_last_error = std::string("hipGetDeviceCount: ") + hipGetErrorString(e);
+    return RTMI_ERR_NO_DEVICE;
+  }
+  return n;
+}
+
+extern "C" int32_t rtmi_samples_per_pixel(double s) {
+  if (!(s > 0.0) || s > 1.0) return RTMI_ERR_INVALID_ARGUMENT;
+  int n = 0;
+  while (fma((double)n, s, 0.0) < 1.0) {
+    if (++n > 64) return RTMI_ERR_UNSUPPORTED;
+  }
+  return n * n;
+}
+
+// Sphere.init(boundingObjects:), Renderables.swift:215-246 with Triangle.getBounds :169-195.
+extern "C" int32_t rtmi_bounding_sphere(const rtmi_triangle* tris, int64_t n, double center[3], double* radius) {
+  if ((!tris && n > 0) || n < 0 || !center || !radius) return RTMI_ERR_INVALID_ARGUMENT;
+  double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int64_t i = 0; i < n; ++i)
+    for (int k = 0; k < 3; ++k)
+      for (int a = 0; a < 3; ++a) {
+        double c = tris[i].v[k][a];
+        if (lo[a] > c) lo[a] = c;
+        if (hi[a] < c) hi[a] = c;
+      }
+  double ext[3];
+  for (int a = 0; a < 3; ++a) ext[a] = fabs(hi[a] - lo[a]);
+  *radius = std::max(ext[0], std::max(ext[1], ext[2])) / 2;
+  for (int a = 0; a < 3; ++a) center[a] = hi[a] - (ext[a] / 2);
+  return RTMI_OK;
+}
+
+extern "C" void rtmi_scene_destroy(rtmi_scene* sc) {
+  if (!sc) return;
+  (void)hipSetDevice(sc->device);
+  if (sc->stream) (void)hipStreamSynchronize(sc->stream);
+  for (auto& g : sc->groups) {
+    (void)hipFree(g.d_group); (void)hipFree(g.d_keep); (void)hipFree(g.d_block_counts);
+    (void)hipFree(g.d_filt); (void)hipFree(g.d_packed_tri); (void)hipFree(g.d_npacked);
+  }
+  (void)hipFree(sc->d_objects); (void)hipFree(sc->d_lights); (void)hipFree(sc->d_materials);
+  (void)hipFree(sc->d_tris); (void)hipFree(sc->d_planes); (void)hipFree(sc->d_tri_owner);
+  (void)hipFree(sc->d_hit_id); (void)hipFree(sc->d_tri_hit); (void)hipFree(sc->d_q_child);
+  (void)hipFree(sc->d_q_shade); (void)hipFree(sc->d_q_top); (void)hipFree(sc->d_rgb);
+  (void)hipFree(sc->d_blocks); (void)hipFree(sc->d_cnt);
+  if (sc->ev_a) (void)hipEventDestroy(sc->ev_a);
+  if (sc->ev_b) (void)hipEventDestroy(sc->ev_b);
+  if (sc->ev_c) (void)hipEventDestroy(sc->ev_c);
+  if (sc->ev_d) (void)hipEventDestroy(sc->ev_d);
+  if (sc->stream) (void)hipStreamDestroy(sc->stream);
+  delete sc;
+}
+
+static int32_t scene_create_impl(const rtmi_scene_desc* desc, int32_t device, rtmi_scene* sc) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    g_last_error = "no HIP device visible";
+    return RTMI_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= ndev) return RTMI_ERR_INVALID_ARGUMENT;
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
+    g_last_error = std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
+    return RTMI_ERR_NO_DEVICE;
+  }
+  sc->device = device;
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreate(&sc->ev_a));
+  HIP_TRY(hipEventCreate(&sc->ev_b));
+  HIP_TRY(hipEventCreate(&sc->ev_c));
+  HIP_TRY(hipEventCreate(&sc->ev_d));
+
+  sc->objects.assign(desc->objects, desc->objects + desc->n_objects);
+  sc->n_lights = desc->n_lights;
+  sc->n_materials = desc->n_materials;
+  sc->n_tris = desc->n_triangles;
+
+  auto upload = [&](void** dst, const void* src, size_t bytes) -> int32_t {
+    *dst = nullptr;
+    if (bytes == 0) return RTMI_OK;
+    HIP_TRY(hipMalloc(dst, bytes));
+    HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+    return RTMI_OK;
+  };
+  int32_t rc;
+  if ((rc = upload((void**)&sc->d_objects, desc->objects, sizeof(rtmi_object) * desc->n_objects))) return rc;
+  if ((rc = upload((void**)&sc->d_lights, desc->lights, sizeof(rtmi_light) * desc->n_lights))) return rc;
+  if ((rc = upload((void**)&sc->d_materials, desc->materials, sizeof(rtmi_material) * desc->n_materials))) return rc;
+  if ((rc = upload((void**)&sc->d_tris, desc->triangles, sizeof(rtmi_triangle) * desc->n_triangles))) return rc;
+
+  // triangle -> owning object; groups
+  std::vector<int> owner((size_t)desc->n_triangles, 0x7fffffff);
+  std::vector<int> top;
+  sc->groups.clear();
+  sc->groups.emplace_back();
+  sc->groups[0].object = -1;
+  int n_sphere_like = 0;
+  std::vector<std::vector<int>> child_lists;
+  for (int64_t k = 0; k < desc->n_objects; ++k) {
+    const rtmi_object& ob = desc->objects[k];
+    if (ob.kind == RTMI_TRIANGLES) {
+      for (int64_t i = ob.first; i < ob.first + ob.count; ++i) {
+        top.push_back((int)i);
+        // a triangle listed by several runs keeps its first (lowest) position
+        owner[i] = std::min(owner[i], (int)k);
+      }
+    } else {
+      ++n_sphere_like;
+      if (ob.kind == RTMI_BOUNDING_SPHERE) {
+        TriGroup g;
+        g.object = (int)k;
+        sc->groups.push_back(g);
+        std::vector<int> idx;
+        for (int64_t i = ob.first; i < ob.first + ob.count; ++i) idx.push_back((int)i);
+        child_lists.push_back(std::move(idx));
+      }
+    }
+  }
+  // a top-level triangle that appears in two runs would need per-position owners
+  {
+    std::vector<int> sorted = top;
+    std::sort(sorted.begin(), sorted.end());
+    if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end()) return RTMI_ERR_UNSUPPORTED;
+  }
+  if ((rc = alloc_group(sc->groups[0], top))) return rc;
+  for (size_t g = 1; g < sc->groups.size(); ++g)
+    if ((rc = alloc_group(sc->groups[g], child_lists[g - 1]))) return rc;
+  if ((rc = upload((void**)&sc->d_tri_owner, owner.data(), sizeof(int) * owner.size()))) return rc;
+
+  if (desc->n_triangles > 0) {
+    HIP_TRY(hipMalloc(&sc->d_planes, sizeof(TriPlane) * desc->n_triangles));
+    int nb = (int)((desc->n_triangles + 255) / 256);
+    hipLaunchKernelGGL(k_tri_planes, dim3(nb), dim3(256), 0, sc->stream, sc->d_tris, (long long)desc->n_triangles, sc->d_planes);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipMalloc(&sc->d_cnt, sizeof(DevCounters)));
+  HIP_TRY(hipStreamSynchronize(sc->stream));
+
+  sc->dev.objects = sc->d_objects;
+  sc->dev.lights = sc->d_lights;
+  sc->dev.materials = sc->d_materials;
+  sc->dev.tris = sc->d_tris;
+  sc->dev.planes = sc->d_planes;
+  sc->dev.n_objects = (int)desc->n_objects;
+  sc->dev.n_lights = desc->n_lights;
+  sc->dev.n_sphere_like = n_sphere_like;
+  sc->dev.n_top_tris = (long long)top.size();
+  return RTMI_OK;
+}
+
+extern "C" int32_t rtmi_scene_create(const rtmi_scene_desc* desc, int32_t device, rtmi_scene** out) {
+  if (!out) return RTMI_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  int32_t rc = validate_scene(desc);
+  if (rc != RTMI_OK) return rc;
+  rtmi_scene* sc = new (std::nothrow) rtmi_scene();
+  if (!sc) return RTMI_ERR_OUT_OF_MEMORY;
+  rc = scene_create_impl(desc, device, sc);
+  if (rc != RTMI_OK) {
+    rtmi_scene_destroy(sc);
+    return rc;
+  }
+  *out = sc;
+  return RTMI_OK;
+}
+
+static int32_t ensure_buffers(rtmi_scene* sc, size_t samples, size_t blocks) {
+  if (samples > sc->cap_samples) {
+    (void)hipFree(sc->d_hit_id); (void)hipFree(sc->d_tri_hit); (void)hipFree(sc->d_q_child);
+    (void)hipFree(sc->d_q_shade); (void)hipFree(sc->d_q_top); (void)hipFree(sc->d_rgb);
+    sc->d_hit_id = sc->d_tri_hit = sc->d_q_child = sc->d_q_shade = sc->d_q_top = nullptr;
+    sc->d_rgb = nullptr;
+    sc->cap_samples = 0;
+    HIP_TRY(hipMalloc(&sc->d_hit_id, sizeof(int) * samples));
+    HIP_TRY(hipMalloc(&sc->d_tri_hit, sizeof(int) * samples));
+    HIP_TRY(hipMalloc(&sc->d_q_child, sizeof(int) * samples));
+    HIP_TRY(hipMalloc(&sc->d_q_shade, sizeof(int) * samples));
+    HIP_TRY(hipMalloc(&sc->d_q_top, sizeof(int) * samples));
+    HIP_TRY(hipMalloc(&sc->d_rgb, sizeof(double) * 3 * samples));
+    sc->cap_samples = samples;
+  }
+  if (blocks > sc->cap_blocks) {
+    (void)hipFree(sc->d_blocks);
+    sc->d_blocks = nullptr;
+    sc->cap_blocks = 0;
+    HIP_TRY(hipMalloc(&sc->d_blocks, sizeof(int2) * blocks));
+    sc->cap_blocks = blocks;
+  }
+  return RTMI_OK;
+}
+
+// Run pack for one group against the frame's camera.
+static int32_t pack_group(rtmi_scene* sc, TriGroup& g, d3 cam) {
+  if (g.n == 0) return RTMI_OK;
+  int nblocks = (g.n + 255) / 256;
+  HIP_TRY(hipMemsetAsync(g.d_filt, 0xFF, g.filt_bytes, sc->stream));  // all-ones = NaN: never nominates
+  hipLaunchKernelGGL(k_pack_flags, dim3(nblocks), dim3(256), 0, sc->stream, sc->d_tris, sc->d_planes, g.d_group, g.n,
+                     cam, g.d_keep, g.d_block_counts);
+  hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(1024), 0, sc->stream, g.d_block_counts, nblocks, g.d_npacked);
+  hipLaunchKernelGGL(k_pack_write, dim3(nblocks), dim3(256), 0, sc->stream, sc->d_tris, g.d_group, g.n, cam, g.d_keep,
+                     g.d_block_counts, g.d_filt, g.d_packed_tri);
+  HIP_TRY(hipGetLastError());
+  return RTMI_OK;
+}
+
+constexpr int SEARCH_R = 4;
+constexpr size_t MAX_BATCH_SAMPLES = 1u << 25;  // 32 Mi samples per batch (about 1.2 GB of work buffers)
+
+static int32_t render_impl(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_params* p, void* rgba_dev,
+                           void* hit_dev, rtmi_counters* counters) {
+  if (!sc || !cam || !p || !rgba_dev) return RTMI_ERR_INVALID_ARGUMENT;
+  if (p->width < 2 || p->height < 2) return RTMI_ERR_INVALID_ARGUMENT;
+  if (p->hit_policy != RTMI_HIT_LIST_ORDER) return RTMI_ERR_UNSUPPORTED;
+  int spp = rtmi_samples_per_pixel(p->pixel_subdivision);
+  if (spp < 0) return spp;
+  int n1 = 1;
+  while (n1 * n1 < spp) ++n1;
+  int x0 = p->x0, y0 = p->y0, x1 = p->x1, y1 = p->y1;
+  if (x0 == 0 && y0 == 0 && x1 == 0 && y1 == 0) { x1 = p->width - 1; y1 = p->height - 1; }
+  if (x0 < 0 || y0 < 0 || x1 > p->width - 1 || y1 > p->height - 1 || x0 > x1 || y0 > y1) return RTMI_ERR_INVALID_ARGUMENT;
+  if (p->tile_size < 0 || p->tile_world < 0 || (p->tile_world > 1 && (p->tile_rank < 0 || p->tile_rank >= p->tile_world)))
+    return RTMI_ERR_INVALID_ARGUMENT;
+  if (p->tile_world > 1 && p->tile_size <= 0) return RTMI_ERR_INVALID_ARGUMENT;
+
+  std::lock_guard<std::mutex> lock(sc->mu);
+  HIP_TRY(hipSetDevice(sc->device));
+
+  // camera frame: RayTracingFunctions.swift:156-170, WorldCoordinateSequence.swift:58-59
+  FrameConst fc{};
+  {
+    d3 camera = rtx::ld3(cam->pos);
+    d3 center = rtx::add(camera, rtx::smul(cam->focal_length, rtx::ld3(cam->dir)));
+    d3 u, v;
+    rtx::plane_vectors(rtx::ld3(cam->dir), &u, &v);
+    d3 hpc = rtx::muls(u, 10.0 / 2.0), vpc = rtx::muls(v, 10.0 / 2.0);
+    d3 ul = rtx::add(rtx::sub(center, hpc), vpc);
+    d3 ur = rtx::add(rtx::add(center, hpc), vpc);
+    d3 ll = rtx::sub(rtx::sub(center, hpc), vpc);
+    fc.ul[0] = ul.x; fc.ul[1] = ul.y; fc.ul[2] = ul.z;
+    fc.u[0] = u.x; fc.u[1] = u.y; fc.u[2] = u.z;
+    fc.v[0] = v.x; fc.v[1] = v.y; fc.v[2] = v.z;
+    fc.cam[0] = camera.x; fc.cam[1] = camera.y; fc.cam[2] = camera.z;
+    fc.ppw_h = (double)(p->width - 1) / sqrt(rtx::len_squared(rtx::sub(ur, ul)));
+    fc.ppw_v = (double)(p->height - 1) / sqrt(rtx::len_squared(rtx::sub(ll, ul)));
+  }
+  fc.sub = p->pixel_subdivision;
+  for (int a = 0; a < 3; ++a) fc.ambient[a] = p->ambient[a];
+  fc.W = p->width; fc.H = p->height;
+  fc.x0 = x0; fc.y0 = y0; fc.x1 = x1; fc.y1 = y1;
+  fc.spp = spp; fc.n1 = n1;
+  fc.tile_size = p->tile_size;
+  fc.tiles_x = p->tile_size > 0 ? (p->width - 1 + p->tile_size - 1) / p->tile_size : 1;
+  fc.tile_rank = p->tile_rank;
+  fc.tile_world = p->tile_world > 1 ? p->tile_world : 1;
+
+  // 8x8 pixel blocks that contain at least one pixel to render
+  std::vector<int2> blocks;
+  {
+    const bool tiled = fc.tile_world > 1;
+    const bool aligned = tiled && (fc.tile_size % BLK == 0);
+    for (int by = y0 / BLK; by * BLK < y1; ++by)
+      for (int bx = x0 / BLK; bx * BLK < x1; ++bx) {
+        if (aligned) {
+          int tile = ((by * BLK) / fc.tile_size) * fc.tiles_x + (bx * BLK) / fc.tile_size;
+          if (tile % fc.tile_world != fc.tile_rank) continue;
+        }
+        blocks.push_back(make_int2(bx, by));
+      }
+  }
+  const size_t samples_per_block = (size_t)BLK_PIX * spp;
+  const size_t blocks_per_batch = std::max<size_t>(1, MAX_BATCH_SAMPLES / samples_per_block);
+  const size_t max_batch_blocks = std::min(blocks_per_batch, std::max<size_t>(blocks.size(), 1));
+  int32_t rc = ensure_buffers(sc, max_batch_blocks * samples_per_block, std::max<size_t>(blocks.size(), 1));
+  if (rc) return rc;
+
+  hipStream_t st = sc->stream;
+  HIP_TRY(hipEventRecord(sc->ev_a, st));
+  HIP_TRY(hipMemsetAsync(sc->d_cnt, 0, sizeof(DevCounters), st));
+  if (!blocks.empty())
+    HIP_TRY(hipMemcpyAsync(sc->d_blocks, blocks.data(), sizeof(int2) * blocks.size(), hipMemcpyHostToDevice, st));
+
+  d3 camera = rtx::ld3(cam->pos);
+  for (auto& g : sc->groups)
+    if ((rc = pack_group(sc, g, camera))) return rc;
+
+  float ms_search = 0.f, ms_primary = 0.f;
+  long long launches = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;
+
+  for (size_t b0 = 0; b0 < blocks.size(); b0 += blocks_per_batch) {
+    size_t nb = std::min(blocks_per_batch, blocks.size() - b0);
+    int nsamples = (int)(nb * samples_per_block);
+    const int2* d_blk = sc->d_blocks + b0;
+    HIP_TRY(hipMemsetAsync(&sc->d_cnt->q_child, 0, sizeof(int) * 3, st));
+    int grid = (nsamples + 255) / 256;
+    hipLaunchKernelGGL(k_gen, dim3(grid), dim3(256), 0, st, fc, sc->dev, d_blk, nsamples, sc->d_hit_id, sc->d_q_child,
+                       sc->d_q_shade, sc->d_q_top, sc->d_cnt);
+    const int search_grid = (nsamples + 256 * SEARCH_R - 1) / (256 * SEARCH_R);
+    if (sc->groups[0].n > 0) {
+      TriGroup& g = sc->groups[0];
+      hipEvent_t e0, e1;
+      HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+      HIP_TRY(hipEventRecord(e0, st));
+      hipLaunchKernelGGL(k_search_primary<SEARCH_R>, dim3(search_grid), dim3(256), 0, st, fc, sc->dev, d_blk, sc->d_q_top,
+                         &sc->d_cnt->q_top, 1, -1, (const f2*)g.d_filt, g.d_npacked, g.d_packed_tri,
+                         sc->d_hit_id, sc->d_tri_hit, sc->d_q_shade, sc->d_cnt);
+      HIP_TRY(hipEventRecord(e1, st));
+      timed.emplace_back(e0, e1);
+      ++launches;
+      hipLaunchKernelGGL(k_resolve_top, dim3(grid), dim3(256), 0, st, sc->dev, sc->d_q_top, &sc->d_cnt->q_top, sc->d_tri_hit,
+                         sc->d_tri_owner, sc->d_hit_id, sc->d_q_child, sc->d_q_shade, sc->d_cnt);
+    }
+    for (size_t gi = 1; gi < sc->groups.size(); ++gi) {
+      TriGroup& g = sc->groups[gi];
+      hipEvent_t e0, e1;
+      HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+      HIP_TRY(hipEventRecord(e0, st));
+      hipLaunchKernelGGL(k_search_primary<SEARCH_R>, dim3(search_grid), dim3(256), 0, st, fc, sc->dev, d_blk, sc->d_q_child,
+                         &sc->d_cnt->q_child, 0, g.object, (const f2*)g.d_filt, g.d_npacked, g.d_packed_tri,
+                         sc->d_hit_id, sc->d_tri_hit, sc->d_q_shade, sc->d_cnt);
+      HIP_TRY(hipEventRecord(e1, st));
+      timed.emplace_back(e0, e1);
+      ++launches;
+    }
+    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(256), 0, st, fc, sc->dev, d_blk, sc->d_q_shade, &sc->d_cnt->q_shade,
+                       sc->d_hit_id, sc->d_rgb, sc->d_cnt);
+    int npix = (int)(nb * BLK_PIX);
+    hipLaunchKernelGGL(k_resolve, dim3((npix + 255) / 256), dim3(256), 0, st, fc, d_blk, npix, sc->d_hit_id, sc->d_rgb,
+                       (unsigned char*)rgba_dev, (int*)hit_dev);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipEventRecord(sc->ev_b, st));
+  DevCounters hc;
+  HIP_TRY(hipMemcpyAsync(&hc, sc->d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  float ms_total = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms_total, sc->ev_a, sc->ev_b));
+  for (auto& pr : timed) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
+    ms_search += ms;
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
+  ms_primary = ms_search;
+  if (counters) {
+    memset(counters, 0, sizeof(*counters));
+    counters->samples = (int64_t)hc.samples;
+    counters->rays_reflection = (int64_t)hc.rays_reflection;
+    counters->rays_shadow = (int64_t)hc.rays_shadow;
+    counters->tri_tests = (int64_t)(hc.tri_tests + hc.tri_tests_primary_kernel);
+    counters->sphere_tests = (int64_t)hc.sphere_tests;
+    counters->tri_exact_tests = (int64_t)hc.tri_exact_tests;
+    counters->primary_hits = (int64_t)hc.primary_hits;
+    counters->ms_total = ms_total;
+    counters->ms_tri_search = ms_search;
+    counters->tri_search_launches = launches;
+    counters->tri_tests_primary_kernel = (int64_t)hc.tri_tests_primary_kernel;
+    counters->ms_primary_kernel = ms_primary;
+  }
+  return RTMI_OK;
+}
+
+extern "C" int32_t rtmi_render_device(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_params* p, void* rgba_dev,
+                                      void* hit_dev, rtmi_counters* counters) {
+  return render_impl(sc, cam, p, rgba_dev, hit_dev, counters);
+}
+
+extern "C" int32_t rtmi_render(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_params* p, uint8_t* rgba_out,
+                               int32_t* hit_id_out, rtmi_counters* counters) {
+  if (!sc || !p || !rgba_out) return RTMI_ERR_INVALID_ARGUMENT;
+  if (p->width < 2 || p->height < 2) return RTMI_ERR_INVALID_ARGUMENT;
+  int spp = rtmi_samples_per_pixel(p->pixel_subdivision);
+  if (spp < 0) return spp;
+  HIP_TRY(hipSetDevice(sc->device));
+  size_t nbytes = (size_t)4 * p->width * p->height;
+  size_t nhit = (size_t)p->width * p->height * spp;
+  unsigned char* d_rgba = nullptr;
+  int* d_hit = nullptr;
+  HIP_TRY(hipMalloc(&d_rgba, nbytes));
+  hipError_t e = hipMemcpy(d_rgba, rgba_out, nbytes, hipMemcpyHostToDevice);  // unrendered pixels keep the caller's bytes
+  if (e == hipSuccess && hit_id_out) {
+    e = hipMalloc(&d_hit, sizeof(int) * nhit);
+    if (e == hipSuccess) e = hipMemcpy(d_hit, hit_id_out, sizeof(int) * nhit, hipMemcpyHostToDevice);
+  }
+  int32_t rc = RTMI_OK;
+  if (e != hipSuccess) {
+    g_last_error = std::string("rtmi_render staging: ") + hipGetErrorString(e);
+    rc = e == hipErrorOutOfMemory ? RTMI_ERR_OUT_OF_MEMORY : RTMI_ERR_HIP;
+  }
+  if (rc == RTMI_OK) rc = render_impl(sc, cam, p, d_rgba, d_hit, counters);
+  if (rc == RTMI_OK) {
+    e = hipMemcpy(rgba_out, d_rgba, nbytes, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && hit_id_out) e = hipMemcpy(hit_id_out, d_hit, sizeof(int) * nhit, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+      g_last_error = std::string("rtmi_render readback: ") + hipGetErrorString(e);
+      rc = RTMI_ERR_HIP;
+    }
+  }
+  (void)hipFree(d_rgba);
+  (void)hipFree(d_hit);
+  return rc;
+}

@@ -1,0 +1,175 @@
+// rtmi_exact.h -- FP64 evaluation of the reference's intersection and shading arithmetic,
+// operation for operation, for host and gfx950 device code.
+//
+// These functions decide every result the library returns: the FP32 packed filter in
+// rtmi.hip only nominates (ray, triangle) pairs, and each nominee is re-decided here with
+// the reference's own formulas, operand order and divisions.  The translation unit must be
+// built with -ffp-contract=off (the reference never fuses a*b+c); sqrt and / on gfx950
+// double are correctly rounded, so the bits match a host evaluation.
+//
+// Citations: RTF = RayTraceUI/RayTracingFunctions.swift, REN = RayTraceUI/Renderables.swift,
+// WCS = RayTraceUI/WorldCoordinateSequence.swift, UTL = RayTraceUI/Utilities.swift.
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define RT_HD __host__ __device__ inline
+#else
+#define RT_HD inline
+#endif
+
+namespace rtx {
+
+struct d3 {
+  double x, y, z;
+};
+
+RT_HD d3 mk(double x, double y, double z) { d3 r; r.x = x; r.y = y; r.z = z; return r; }
+RT_HD d3 ld3(const double* p) { return mk(p[0], p[1], p[2]); }
+RT_HD d3 add(d3 a, d3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_HD d3 sub(d3 a, d3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_HD d3 neg(d3 a) { return mk(-a.x, -a.y, -a.z); }
+RT_HD d3 smul(double s, d3 a) { return mk(s * a.x, s * a.y, s * a.z); }  // scalar * vector
+RT_HD d3 muls(d3 a, double s) { return mk(a.x * s, a.y * s, a.z * s); }  // vector * scalar
+RT_HD d3 divs(d3 a, double s) { return mk(a.x / s, a.y / s, a.z / s); }  // vector / scalar
+
+// dp, UTL:23-25
+RT_HD double dp(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// lenSquared, UTL:38-40
+RT_HD double len_squared(d3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+// normalize, UTL:27-30 (three true divisions by the square root)
+RT_HD d3 normalize(d3 a) {
+  double length = sqrt(dp(a, a));
+  return mk(a.x / length, a.y / length, a.z / length);
+}
+// cross, UTL:32-36
+RT_HD d3 cross(d3 a, d3 b) {
+  return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+// clampFunction(0, 1), UTL:67-78
+RT_HD double clamp01(double v) {
+  if (v < 0.0) return 0.0;
+  if (v > 1.0) return 1.0;
+  return v;
+}
+
+// The ray-independent head of Triangle.intersections (REN:137-143): unit normal and plane
+// constant.  Evaluated once per triangle; the bits equal a per-call evaluation.
+struct TriPlane {
+  double nx, ny, nz, c;
+};
+
+RT_HD TriPlane tri_plane(d3 v0, d3 v1, d3 v2) {
+  d3 v0v1 = sub(v1, v0);
+  d3 v0v2 = sub(v2, v0);
+  d3 n = normalize(cross(v0v1, v0v2));
+  TriPlane p;
+  p.nx = n.x; p.ny = n.y; p.nz = n.z;
+  p.c = dp(n, v0);
+  return p;
+}
+
+// The rest of Triangle.intersections (REN:144-166).  Returns true on a hit and then sets
+// *t and *P (the normal of the hit is the plane normal).
+RT_HD bool tri_hit(d3 v0, d3 v1, d3 v2, const TriPlane& pl, d3 origin, d3 direction, double* t_out,
+                   d3* P_out) {
+  d3 normal = mk(pl.nx, pl.ny, pl.nz);
+  double nddot = dp(normal, neg(direction));
+  if (!(nddot > 0)) return false;  // REN:146 `nddot <= 0 -> return`; NaN falls through there
+                                   // and fails `t > 0` below, so no hit either way
+  double t = (pl.c - dp(normal, origin)) / -nddot;
+  if (t > 0) {
+    d3 v0v1 = sub(v1, v0);
+    d3 v0v2 = sub(v2, v0);
+    d3 v1v2 = sub(v2, v1);
+    d3 v2v0 = neg(v0v2);
+    d3 point = add(origin, smul(t, direction));
+    d3 v0p = sub(point, v0);
+    d3 v1p = sub(point, v1);
+    d3 v2p = sub(point, v2);
+    d3 a = cross(v0v1, v0p);
+    d3 b = cross(v1v2, v1p);
+    d3 c = cross(v2v0, v2p);
+    if (dp(a, normal) >= 0 && dp(b, normal) >= 0 && dp(c, normal) >= 0) {
+      *t_out = t;
+      *P_out = point;
+      return true;
+    }
+  }
+  return false;
+}
+
+// Sphere.intersections (REN:248-282) reduced to its first element: the smallest root that
+// passes the >= 1e-7 filter, with its point and outward normal.
+RT_HD bool sphere_first(d3 location, double radius, d3 origin, d3 direction, double* t_out,
+                        d3* P_out, d3* n_out) {
+  double radius_squared = radius * radius;  // pow(radius, 2), REN:210/:243
+  d3 center_to_eye = sub(origin, location);
+  double a = -dp(direction, center_to_eye);
+  double delta = a * a - (len_squared(center_to_eye) - radius_squared);  // pow(a, 2)
+  if (!(delta >= 0)) return false;  // REN:255 `delta < 0 -> return`; NaN: sqrt(NaN) roots fail the filter
+  double sqrtdelta = sqrt(delta);
+  double r0, r1;
+  int nr;
+  if (delta == 0) {
+    r0 = a; r1 = a; nr = 1;
+  } else {
+    double t1 = a + sqrtdelta, t2 = a - sqrtdelta;
+    if (t1 < t2) { r0 = t1; r1 = t2; } else { r0 = t2; r1 = t1; }
+    nr = 2;
+  }
+  double t;
+  if (r0 >= 0.0000001) t = r0;
+  else if (nr == 2 && r1 >= 0.0000001) t = r1;
+  else return false;
+  d3 p = add(origin, smul(t, direction));
+  *t_out = t;
+  *P_out = p;
+  *n_out = normalize(sub(p, location));
+  return true;
+}
+
+// Whether Sphere.intersections appends anything (used by shadow rays, RTF:236-243).
+RT_HD bool sphere_any(d3 location, double radius, d3 origin, d3 direction) {
+  double radius_squared = radius * radius;
+  d3 center_to_eye = sub(origin, location);
+  double a = -dp(direction, center_to_eye);
+  double delta = a * a - (len_squared(center_to_eye) - radius_squared);
+  if (!(delta >= 0)) return false;
+  double sqrtdelta = sqrt(delta);
+  if (delta == 0) return a >= 0.0000001;
+  double t1 = a + sqrtdelta, t2 = a - sqrtdelta;
+  return t1 >= 0.0000001 || t2 >= 0.0000001;
+}
+
+// PointLight.intersections (REN:80-91) with eq3 (UTL:155-157).
+RT_HD bool light_hit(d3 location, d3 origin, d3 direction, double* t_out, d3* P_out) {
+  d3 num = sub(location, origin);
+  double tx = num.x / direction.x, ty = num.y / direction.y, tz = num.z / direction.z;
+  if (tx >= 0.0000001 && (!isinf(tx) && tx == ty && ty == tz)) {
+    *t_out = tx;
+    *P_out = add(origin, smul(tx, direction));
+    return true;
+  }
+  return false;
+}
+
+// getPlaneVectors (RTF:46-57).
+RT_HD void plane_vectors(d3 direction, d3* u_out, d3* v_out) {
+  d3 plane_normal = normalize(neg(direction));
+  d3 up = normalize(mk(0.0, 1.0, -1.0));
+  d3 u = normalize(cross(up, plane_normal));
+  *u_out = u;
+  *v_out = cross(plane_normal, u);
+}
+
+// pixelToWorldCoordinate (WCS:62-66).
+RT_HD d3 pixel_to_world(d3 ul, d3 u, d3 v, double ppw_h, double ppw_v, double i, double j) {
+  d3 uc = divs(muls(u, i), ppw_h);
+  d3 vc = divs(muls(v, j), ppw_v);
+  return sub(add(ul, uc), vc);
+}
+
+}  // namespace rtx
