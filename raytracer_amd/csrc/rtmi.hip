@@ -762,16 +762,19 @@ static int32_t validate_scene(const rtmi_scene_desc* s) {
 }
 
 static int32_t alloc_group(TriGroup& g, const std::vector<int>& idx) {
+  // An empty group (a bounding sphere without children) still gets its buffers: the search
+  // kernel then runs with npacked == 0 and resolves every queued sample as a miss.
   g.n = (int)idx.size();
-  if (g.n == 0) return RTMI_OK;
-  int nblocks = (g.n + 255) / 256;
-  HIP_TRY(hipMalloc(&g.d_group, sizeof(int) * g.n));
-  HIP_TRY(hipMemcpy(g.d_group, idx.data(), sizeof(int) * g.n, hipMemcpyHostToDevice));
-  HIP_TRY(hipMalloc(&g.d_keep, g.n));
+  const size_t n1 = std::max<size_t>(g.n, 1);
+  const int nblocks = (int)((n1 + 255) / 256);
+  HIP_TRY(hipMalloc(&g.d_group, sizeof(int) * n1));
+  if (g.n) HIP_TRY(hipMemcpy(g.d_group, idx.data(), sizeof(int) * g.n, hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&g.d_keep, n1));
   HIP_TRY(hipMalloc(&g.d_block_counts, sizeof(int) * nblocks));
   g.filt_bytes = sizeof(float) * FILT_FLOATS * ((size_t)(g.n + TRI_BATCH - 1) / TRI_BATCH + 2);
   HIP_TRY(hipMalloc(&g.d_filt, g.filt_bytes));
-  HIP_TRY(hipMalloc(&g.d_packed_tri, sizeof(int) * g.n));
+  HIP_TRY(hipMemset(g.d_filt, 0xFF, g.filt_bytes));
+  HIP_TRY(hipMalloc(&g.d_packed_tri, sizeof(int) * n1));
   HIP_TRY(hipMalloc(&g.d_npacked, sizeof(int)));
   HIP_TRY(hipMemset(g.d_npacked, 0, sizeof(int)));
   return RTMI_OK;
