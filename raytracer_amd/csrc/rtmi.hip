@@ -65,9 +65,13 @@ struct FrameConst {
   int tile_size, tiles_x, tile_rank, tile_world;
 };
 
+// Work counters are striped over NSLOT cache lines (one 64-byte line per slot) so that the
+// per-wave atomic adds of a launch do not serialise on one address; the host sums the slots.
+enum { C_REFL = 0, C_SHADOW, C_EXACT, C_HITS, C_TESTS_PRIMARY, C_NCOUNTERS = 8 };
+constexpr int NSLOT = 64;
+
 struct DevCounters {
-  unsigned long long samples, rays_reflection, rays_shadow, tri_tests, sphere_tests,
-      tri_exact_tests, primary_hits, tri_tests_primary_kernel;
+  unsigned long long slot[NSLOT][C_NCOUNTERS];
   int q_child, q_shade, q_top;  // queue fill levels
   int pad;
 };
@@ -113,21 +117,35 @@ __device__ inline d3 sample_dir(const FrameConst& fc, int x, int y, int k) {
   return rtx::normalize(rtx::sub(p, rtx::ld3(fc.cam)));
 }
 
-__device__ inline void wave_append(int* counter, int* queue, bool pred, int value) {
-  unsigned long long mask = __ballot(pred);
-  if (mask == 0) return;
-  int lane = threadIdx.x & 63;
-  int leader = __ffsll((long long)mask) - 1;
-  int base = 0;
-  if (lane == leader) base = atomicAdd(counter, __popcll(mask));
-  base = __shfl(base, leader);
-  if (pred) queue[base + __popcll(mask & ((1ull << lane) - 1ull))] = value;
+// Sum v over the wave and add it to this wave's stripe of counter `idx`.
+__device__ inline void wave_count(DevCounters* cnt, int idx, unsigned long long v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+  if ((threadIdx.x & 63) == 0 && v) {
+    int slot = (blockIdx.x * 4 + (threadIdx.x >> 6)) & (NSLOT - 1);
+    atomicAdd(&cnt->slot[slot][idx], v);
+  }
 }
 
-__device__ inline void wave_count(unsigned long long* counter, unsigned long long v) {
-  // sum v over the active lanes, one atomic per wave
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-  if ((threadIdx.x & 63) == 0 && v) atomicAdd(counter, v);
+// Append `value` of every thread with `pred` to a global queue with ONE returning atomic per
+// 256-thread workgroup.  Must be reached by all threads of the workgroup.
+__device__ inline void block_append(int* counter, int* queue, bool pred, int value) {
+  __shared__ int wtot[4];
+  __shared__ int gbase;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  unsigned long long mask = __ballot(pred);
+  if (lane == 0) wtot[w] = __popcll(mask);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tot = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    gbase = tot ? atomicAdd(counter, tot) : 0;
+  }
+  __syncthreads();
+  if (pred) {
+    int pos = gbase + __popcll(mask & ((1ull << lane) - 1ull));
+    for (int q = 0; q < w; ++q) pos += wtot[q];
+    queue[pos] = value;
+  }
+  __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------
@@ -336,33 +354,60 @@ __device__ inline bool trace_top_secondary(const SceneDev& sc, d3 o, d3 d, bool 
 // With no top-level triangle runs the sample is resolved here: a sphere or light hit goes to
 // the shade queue, a bounding-sphere hit to the child-search queue.  With top-level runs
 // every rendered sample goes on to the top-level triangle search, which resolves it.
+constexpr int GEN_ITERS = 8;  // samples per thread in k_gen; a workgroup covers 2048 consecutive samples
+
 __global__ void __launch_bounds__(256)
 k_gen(FrameConst fc, SceneDev sc, const int2* __restrict__ blocks, int nsamples, int* hit_id, int* q_child,
       int* q_shade, int* q_top, DevCounters* cnt) {
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
-  int x, y, k;
-  bool live = s < nsamples && sample_coords(fc, blocks, s, &x, &y, &k);
-  int id = -1;
-  bool to_child = false, to_shade = false;
-  if (live) {
-    d3 d = sample_dir(fc, x, y, k);
-    Hit h;
-    int obj = first_sphere_like(sc, rtx::ld3(fc.cam), d, &h);
-    if (obj >= 0) {
-      id = -2 - obj;
-      if (sc.objects[obj].kind == RTMI_BOUNDING_SPHERE) to_child = true; else to_shade = true;
+  // queue entries are staged in LDS and flushed with one global atomic per queue per workgroup
+  __shared__ int lq[3][256 * GEN_ITERS];
+  __shared__ int ln[3];
+  __shared__ int lbase[3];
+  if (threadIdx.x < 3) ln[threadIdx.x] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const bool has_top = sc.n_top_tris > 0;
+  for (int it = 0; it < GEN_ITERS; ++it) {
+    int s = (blockIdx.x * GEN_ITERS + it) * 256 + threadIdx.x;
+    int x, y, k;
+    bool live = s < nsamples && sample_coords(fc, blocks, s, &x, &y, &k);
+    int id = -1;
+    bool to_child = false, to_shade = false;
+    if (live) {
+      d3 d = sample_dir(fc, x, y, k);
+      Hit h;
+      int obj = first_sphere_like(sc, rtx::ld3(fc.cam), d, &h);
+      if (obj >= 0) {
+        id = -2 - obj;
+        if (sc.objects[obj].kind == RTMI_BOUNDING_SPHERE) to_child = true; else to_shade = true;
+      }
+    }
+    if (s < nsamples) hit_id[s] = id;
+    // with top-level triangle runs every live sample is resolved after their search
+    bool pred[3] = {!has_top && to_child, !has_top && to_shade, has_top && live};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      unsigned long long mask = __ballot(pred[q]);
+      if (mask) {
+        int leader = __ffsll((long long)mask) - 1;
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&ln[q], __popcll(mask));
+        base = __shfl(base, leader);
+        if (pred[q]) lq[q][base + __popcll(mask & ((1ull << lane) - 1ull))] = s;
+      }
     }
   }
-  if (s < nsamples) hit_id[s] = live ? id : -1;
-  if (sc.n_top_tris > 0) {
-    // resolved after the top-level triangle search (k_resolve_top)
-    wave_append(&cnt->q_top, q_top, live, s);
-  } else {
-    wave_append(&cnt->q_child, q_child, to_child, s);
-    wave_append(&cnt->q_shade, q_shade, to_shade, s);
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    int* gcount = threadIdx.x == 0 ? &cnt->q_child : (threadIdx.x == 1 ? &cnt->q_shade : &cnt->q_top);
+    lbase[threadIdx.x] = ln[threadIdx.x] ? atomicAdd(gcount, ln[threadIdx.x]) : 0;
   }
-  wave_count(&cnt->samples, live ? 1ull : 0ull);
-  wave_count(&cnt->sphere_tests, live ? (unsigned long long)sc.n_sphere_like : 0ull);
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    int* gq = q == 0 ? q_child : (q == 1 ? q_shade : q_top);
+    for (int i = threadIdx.x; i < ln[q]; i += 256) gq[lbase[q] + i] = lq[q][i];
+  }
 }
 
 // After the top-level triangle search: combine the first sphere-like object (hit_id from
@@ -385,8 +430,8 @@ k_resolve_top(SceneDev sc, const int* __restrict__ q_top, const int* __restrict_
       if (sc.objects[obj].kind == RTMI_BOUNDING_SPHERE) to_child = true; else to_shade = true;
     }
   }
-  wave_append(&cnt->q_child, q_child, to_child, s);
-  wave_append(&cnt->q_shade, q_shade, to_shade, s);
+  block_append(&cnt->q_child, q_child, to_child, s);
+  block_append(&cnt->q_shade, q_shade, to_shade, s);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -415,9 +460,10 @@ k_search_primary(FrameConst fc, SceneDev sc, const int2* __restrict__ blocks, co
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int base = wave * 64 * R;
-  if (base >= nq) return;
+  if ((int)(blockIdx.x * blockDim.x) * R >= nq) return;  // whole workgroup past the queue end
   const int npacked = *npacked_ptr;
-  const int nbatch = (npacked + TRI_BATCH - 1) / TRI_BATCH;
+  const int nbatch = base < nq ? (npacked + TRI_BATCH - 1) / TRI_BATCH : 0;
+  unsigned long long n_exact = 0;
 
   int sid[R], best[R], upto[R];
   bool valid[R];
@@ -492,7 +538,7 @@ k_search_primary(FrameConst fc, SceneDev sc, const int2* __restrict__ blocks, co
                   const rtmi_triangle& tr = sc.tris[ti];
                   double t;
                   d3 P;
-                  atomicAdd(&cnt->tri_exact_tests, 1ull);
+                  n_exact += 1;
                   if (rtx::tri_hit(rtx::ld3(tr.v[0]), rtx::ld3(tr.v[1]), rtx::ld3(tr.v[2]), sc.planes[ti],
                                    rtx::ld3(fc.cam), d, &t, &P)) {
                     best[r] = ti;
@@ -522,15 +568,40 @@ k_search_primary(FrameConst fc, SceneDev sc, const int2* __restrict__ blocks, co
   for (int r = 0; r < R; ++r) {
     if (valid[r]) tests += best[r] >= 0 ? (unsigned long long)upto[r] : walked;
   }
-  wave_count(&cnt->tri_tests_primary_kernel, tests);
+  wave_count(cnt, C_TESTS_PRIMARY, tests);
+  wave_count(cnt, C_EXACT, n_exact);
 
+  if (mode == 0) {
+    // hits go to the shade queue: one returning atomic per workgroup for all R rays
+    __shared__ int wtot[4];
+    __shared__ int gbase;
+    const int w = threadIdx.x >> 6;
+    unsigned long long masks[R];
+    int wave_total = 0;
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    int q = base + r * 64 + lane;
-    if (mode == 0) {
+    for (int r = 0; r < R; ++r) {
       if (valid[r]) hit_id[sid[r]] = best[r];
-      wave_append(&cnt->q_shade, q_shade, valid[r] && best[r] >= 0, sid[r]);
-    } else {
+      masks[r] = __ballot(valid[r] && best[r] >= 0);
+      wave_total += __popcll(masks[r]);
+    }
+    if (lane == 0) wtot[w] = wave_total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int tot = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+      gbase = tot ? atomicAdd(&cnt->q_shade, tot) : 0;
+    }
+    __syncthreads();
+    int pos = gbase;
+    for (int q = 0; q < w; ++q) pos += wtot[q];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (valid[r] && best[r] >= 0) q_shade[pos + __popcll(masks[r] & ((1ull << lane) - 1ull))] = sid[r];
+      pos += __popcll(masks[r]);
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      int q = base + r * 64 + lane;
       if (q < nq) tri_hit[q] = best[r];
     }
   }
@@ -649,12 +720,9 @@ k_shade(FrameConst fc, SceneDev sc, const int2* __restrict__ blocks, const int* 
     rgb[(size_t)s * 3 + 1] = c.g;
     rgb[(size_t)s * 3 + 2] = c.b;
   }
-  wave_count(&cnt->primary_hits, n_hit);
-  wave_count(&cnt->rays_reflection, n_refl);
-  wave_count(&cnt->rays_shadow, n_shadow);
-  // every secondary ray is tested against every top-level object by the reference
-  wave_count(&cnt->sphere_tests, (n_refl + n_shadow) * (unsigned long long)sc.n_sphere_like);
-  wave_count(&cnt->tri_tests, (n_refl + n_shadow) * (unsigned long long)sc.n_top_tris);
+  wave_count(cnt, C_HITS, n_hit);
+  wave_count(cnt, C_REFL, n_refl);
+  wave_count(cnt, C_SHADOW, n_shadow);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1072,6 +1140,20 @@ static int32_t render_impl(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_pa
         blocks.push_back(make_int2(bx, by));
       }
   }
+  // rendered samples: pixels of the window that this call's tile selection owns
+  int64_t live_samples = 0;
+  if (fc.tile_world > 1) {
+    const int ts = fc.tile_size;
+    for (int ty = y0 / ts; ty * ts < y1; ++ty)
+      for (int tx = x0 / ts; tx * ts < x1; ++tx) {
+        if ((ty * fc.tiles_x + tx) % fc.tile_world != fc.tile_rank) continue;
+        int64_t wx = std::min(x1, (tx + 1) * ts) - std::max(x0, tx * ts);
+        int64_t wy = std::min(y1, (ty + 1) * ts) - std::max(y0, ty * ts);
+        live_samples += wx * wy * spp;
+      }
+  } else {
+    live_samples = (int64_t)(x1 - x0) * (y1 - y0) * spp;
+  }
   const size_t samples_per_block = (size_t)BLK_PIX * spp;
   const size_t blocks_per_batch = std::max<size_t>(1, MAX_BATCH_SAMPLES / samples_per_block);
   const size_t max_batch_blocks = std::min(blocks_per_batch, std::max<size_t>(blocks.size(), 1));
@@ -1098,7 +1180,7 @@ static int32_t render_impl(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_pa
     const int2* d_blk = sc->d_blocks + b0;
     HIP_TRY(hipMemsetAsync(&sc->d_cnt->q_child, 0, sizeof(int) * 3, st));
     int grid = (nsamples + 255) / 256;
-    hipLaunchKernelGGL(k_gen, dim3(grid), dim3(256), 0, st, fc, sc->dev, d_blk, nsamples, sc->d_hit_id, sc->d_q_child,
+    hipLaunchKernelGGL(k_gen, dim3((nsamples + 256 * GEN_ITERS - 1) / (256 * GEN_ITERS)), dim3(256), 0, st, fc, sc->dev, d_blk, nsamples, sc->d_hit_id, sc->d_q_child,
                        sc->d_q_shade, sc->d_q_top, sc->d_cnt);
     const int search_grid = (nsamples + 256 * SEARCH_R - 1) / (256 * SEARCH_R);
     if (sc->groups[0].n > 0) {
@@ -1149,18 +1231,23 @@ static int32_t render_impl(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_pa
   }
   ms_primary = ms_search;
   if (counters) {
+    unsigned long long sum[C_NCOUNTERS] = {0};
+    for (int sl = 0; sl < NSLOT; ++sl)
+      for (int c = 0; c < C_NCOUNTERS; ++c) sum[c] += hc.slot[sl][c];
+    const int64_t secondary = (int64_t)(sum[C_REFL] + sum[C_SHADOW]);
     memset(counters, 0, sizeof(*counters));
-    counters->samples = (int64_t)hc.samples;
-    counters->rays_reflection = (int64_t)hc.rays_reflection;
-    counters->rays_shadow = (int64_t)hc.rays_shadow;
-    counters->tri_tests = (int64_t)(hc.tri_tests + hc.tri_tests_primary_kernel);
-    counters->sphere_tests = (int64_t)hc.sphere_tests;
-    counters->tri_exact_tests = (int64_t)hc.tri_exact_tests;
-    counters->primary_hits = (int64_t)hc.primary_hits;
+    counters->samples = live_samples;
+    counters->rays_reflection = (int64_t)sum[C_REFL];
+    counters->rays_shadow = (int64_t)sum[C_SHADOW];
+    // secondary rays: the reference tests every top-level object (RayTracingFunctions.swift:41-43)
+    counters->tri_tests = (int64_t)sum[C_TESTS_PRIMARY] + secondary * sc->dev.n_top_tris;
+    counters->sphere_tests = (live_samples + secondary) * sc->dev.n_sphere_like;
+    counters->tri_exact_tests = (int64_t)sum[C_EXACT];
+    counters->primary_hits = (int64_t)sum[C_HITS];
     counters->ms_total = ms_total;
     counters->ms_tri_search = ms_search;
     counters->tri_search_launches = launches;
-    counters->tri_tests_primary_kernel = (int64_t)hc.tri_tests_primary_kernel;
+    counters->tri_tests_primary_kernel = (int64_t)sum[C_TESTS_PRIMARY];
     counters->ms_primary_kernel = ms_primary;
   }
   return RTMI_OK;
