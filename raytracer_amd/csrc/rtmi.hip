@@ -53,8 +53,10 @@ static thread_local std::string g_last_error;
 // ---------------------------------------------------------------------------------------
 constexpr int BLK = 8;              // pixel block edge; samples are enumerated block by block
 constexpr int BLK_PIX = BLK * BLK;  // so that 64 consecutive samples are screen neighbours
-constexpr int TRI_BATCH = 4;        // triangles per scalar-load batch of the filter loop
-constexpr int FILT_FLOATS = 9 * TRI_BATCH;  // 3 edge planes x 3 components per triangle
+constexpr int TRI_BATCH = 8;        // triangles per scalar-load batch of the cone loop
+constexpr int CONE_DWORDS = 32;     // per batch: 4 pairs x 3 components x (tri a, tri b) + flag + pad
+constexpr int CONE_FLAG = 24;       // dword index of the batch's "always look closer" flag
+constexpr int EDGE_FLOATS = 9;      // per triangle: 3 scaled edge-plane vectors
 
 struct FrameConst {
   double ul[3], u[3], v[3], cam[3];
@@ -206,18 +208,29 @@ __global__ void k_pack_scan(int* block_counts, int nblocks, int* npacked_out) {
 
 // Write the filter operands of every kept triangle at its compacted position.
 //
-// For a ray from the common origin o with unit direction d, the reference's three inside
-// tests (Renderables.swift:158-163) are equivalent, given n.d < 0, to d.M_i <= 0 with
-// M_0 = (v0-o)x(v1-o), M_1 = (v1-o)x(v2-o), M_2 = (v2-o)x(v0-o): for the plane point P,
-// e01 x (P - v0) = lambda*n and d.(e01 x (P - v0)) = d.((v0-o)x(v1-o)).  The filter
-// evaluates s_i = d.M_i/E_i in FP32 and nominates the pair when max_i s_i <= 1, where
-// E_i = 16*2^-24*|M_i|_1 + 2^-40*L^2 bounds the FP32 evaluation error (operand roundings,
-// one product and two fma roundings: < 8*2^-24*|M_i|_1 for |d_k| <= 1) plus the rounding
-// of the reference's own FP64 formulas (about 2^-46*L^2, L = |o|_1 + max|v|_1).  Every
-// pair the reference accepts is therefore nominated; nominees are re-decided in FP64.
+// Two conservative FP32 tests are prepared per triangle, both for rays from the common
+// origin o with unit direction d.
+//
+// (1) Cone test.  With a, b, c the unit vectors from o to the vertices, axis = normalize(a+b+c)
+//     and cos_t = min(axis.a, axis.b, axis.c), every direction that hits the triangle satisfies
+//     d.axis >= cos_t (the spherical triangle is the convex hull of its corners; valid while
+//     cos_t > 0).  Stored: w = axis / (cos_t - 2^-19); nominate iff d.w >= 1.  The 2^-19 margin
+//     exceeds the FP32 evaluation error of the dot product (< 8*2^-24*|axis|_1 <= 8.3e-7) plus
+//     the FP64 rounding of axis/cos_t and of the reference.  A triangle with cos_t - 2^-19 < 1/16
+//     (it subtends more than ~86 degrees) gets w = NaN and raises its batch's flag instead.
+//
+// (2) Edge test.  The reference's three inside tests (Renderables.swift:158-163) are
+//     equivalent, given n.d < 0, to d.M_i <= 0 with M_0 = (v0-o)x(v1-o), M_1 = (v1-o)x(v2-o),
+//     M_2 = (v2-o)x(v0-o): for the plane point P, e01 x (P - v0) = lambda*n and
+//     d.(e01 x (P - v0)) = d.((v0-o)x(v1-o)).  Stored: M_i/E_i; nominate iff max_i d.(M_i/E_i) <= 1,
+//     where E_i = 16*2^-24*|M_i|_1 + 2^-40*L^2 bounds the FP32 evaluation error (operand
+//     roundings, one product and two fma roundings: < 8*2^-24*|M_i|_1 for |d_k| <= 1) plus the
+//     rounding of the reference's own FP64 formulas (about 2^-46*L^2, L = |o|_1 + max|v|_1).
+//
+// Every pair the reference accepts passes both; pairs that pass both are re-decided in FP64.
 __global__ void k_pack_write(const rtmi_triangle* __restrict__ tris, const int* __restrict__ group, int n,
                              d3 cam, const unsigned char* __restrict__ keep,
-                             const int* __restrict__ block_offsets, float* filt, int* packed_tri) {
+                             const int* __restrict__ block_offsets, float* cone, float* edge, int* packed_tri) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   bool k = i < n && keep[i];
   unsigned long long m = __ballot(k);
@@ -232,6 +245,32 @@ __global__ void k_pack_write(const rtmi_triangle* __restrict__ tris, const int* 
   int ti = group[i];
   const rtmi_triangle& t = tris[ti];
   d3 A = rtx::sub(rtx::ld3(t.v[0]), cam), B = rtx::sub(rtx::ld3(t.v[1]), cam), Cc = rtx::sub(rtx::ld3(t.v[2]), cam);
+
+  // (1) cone
+  {
+    double la = sqrt(rtx::dp(A, A)), lb = sqrt(rtx::dp(B, B)), lc = sqrt(rtx::dp(Cc, Cc));
+    d3 a = rtx::divs(A, la), bb = rtx::divs(B, lb), c = rtx::divs(Cc, lc);
+    d3 sum = rtx::add(rtx::add(a, bb), c);
+    double ls = sqrt(rtx::dp(sum, sum));
+    d3 axis = rtx::divs(sum, ls);
+    double cos_t = fmin(rtx::dp(axis, a), fmin(rtx::dp(axis, bb), rtx::dp(axis, c)));
+    double den = cos_t - 1.9073486328125e-06;  // 2^-19
+    float wx, wy, wz;
+    bool wide = !(den >= 0.0625);  // also true for NaN (a vertex at the origin, cancelling axes)
+    if (!wide) {
+      wx = (float)(axis.x / den); wy = (float)(axis.y / den); wz = (float)(axis.z / den);
+      if (!isfinite(wx) || !isfinite(wy) || !isfinite(wz)) wide = true;
+    }
+    int b = pos / TRI_BATCH, j = pos % TRI_BATCH;
+    float* dst = cone + (size_t)b * CONE_DWORDS + (j >> 1) * 6 + (j & 1);
+    if (wide) {
+      wx = wy = wz = __builtin_nanf("");
+      reinterpret_cast<int*>(cone)[(size_t)b * CONE_DWORDS + CONE_FLAG] = 1;  // benign race: all writers store 1
+    }
+    dst[0] = wx; dst[2] = wy; dst[4] = wz;
+  }
+
+  // (2) edge planes
   d3 M[3] = {rtx::cross(A, B), rtx::cross(B, Cc), rtx::cross(Cc, A)};
   double L = fabs(cam.x) + fabs(cam.y) + fabs(cam.z);
   double lv = 0;
@@ -239,15 +278,14 @@ __global__ void k_pack_write(const rtmi_triangle* __restrict__ tris, const int* 
   L += lv;
   const double eps32 = 5.9604644775390625e-08;     // 2^-24
   const double abs_term = 9.094947017729282e-13;   // 2^-40
-  int b = pos / TRI_BATCH, j = pos % TRI_BATCH;
-  float* dst = filt + (size_t)b * FILT_FLOATS + (j >> 1) * 18 + (j & 1);
+  float* dst = edge + (size_t)pos * EDGE_FLOATS;
   for (int e = 0; e < 3; ++e) {
     double E = 16.0 * eps32 * (fabs(M[e].x) + fabs(M[e].y) + fabs(M[e].z)) + abs_term * L * L;
     float mx = (float)(M[e].x / E), my = (float)(M[e].y / E), mz = (float)(M[e].z / E);
     if (!(E > 0) || !isfinite(mx) || !isfinite(my) || !isfinite(mz)) mx = my = mz = 0.0f;  // always nominate
-    dst[(e * 3 + 0) * 2] = mx;
-    dst[(e * 3 + 1) * 2] = my;
-    dst[(e * 3 + 2) * 2] = mz;
+    dst[e * 3 + 0] = mx;
+    dst[e * 3 + 1] = my;
+    dst[e * 3 + 2] = mz;
   }
   packed_tri[pos] = ti;
 }
@@ -357,8 +395,8 @@ __device__ inline bool trace_top_secondary(const SceneDev& sc, d3 o, d3 d, bool 
 constexpr int GEN_ITERS = 8;  // samples per thread in k_gen; a workgroup covers 2048 consecutive samples
 
 __global__ void __launch_bounds__(256)
-k_gen(FrameConst fc, SceneDev sc, const int2* __restrict__ blocks, int nsamples, int* hit_id, int* q_child,
-      int* q_shade, int* q_top, DevCounters* cnt) {
+k_gen(FrameConst fc, SceneDev sc, const int2* __restrict__ blocks, int nsamples, int* hit_id, double* dirs,
+      int* q_child, int* q_shade, int* q_top, DevCounters* cnt) {
   // queue entries are staged in LDS and flushed with one global atomic per queue per workgroup
   __shared__ int lq[3][256 * GEN_ITERS];
   __shared__ int ln[3];
@@ -375,6 +413,9 @@ k_gen(FrameConst fc, SceneDev sc, const int2* __restrict__ blocks, int nsamples,
     bool to_child = false, to_shade = false;
     if (live) {
       d3 d = sample_dir(fc, x, y, k);
+      dirs[(size_t)s * 3 + 0] = d.x;  // kept for the FP64 decisions of the search and for shading
+      dirs[(size_t)s * 3 + 1] = d.y;
+      dirs[(size_t)s * 3 + 2] = d.z;
       Hit h;
       int obj = first_sphere_like(sc, rtx::ld3(fc.cam), d, &h);
       if (obj >= 0) {
@@ -438,24 +479,34 @@ k_resolve_top(SceneDev sc, const int* __restrict__ q_top, const int* __restrict_
 // k_search_primary: the hot kernel
 // ---------------------------------------------------------------------------------------
 // Each lane owns R rays (queue entries base + r*64 + lane) that share the camera origin.
-// Triangles arrive four at a time as 18 float2 = 9 x (tri a, tri b) + 9 x (tri c, tri d),
-// wave-uniform, so the compiler keeps them in SGPRs (s_load_dwordx16) and feeds them to
-// v_pk_mul_f32 / v_pk_fma_f32 as the scalar operand; the next batch is loaded while the
-// current one is evaluated.  Per (ray, triangle): 4.5 packed FMA-class instructions,
-// one v_max3_f32 and half a v_min3_f32.  A lane whose running minimum drops to <= 1 takes
-// the rare path: find the nominee(s), re-test each in FP64 in list order, keep the first
-// hit, and poison the ray direction with NaN so that ray nominates nothing afterwards.
-// The wave leaves the loop once every one of its rays has a hit.
+// Every (ray, triangle) pair goes through a cascade of three tests, cheapest first:
+//
+//   cone   FP32, packed: d.w >= 1            3 FMA per pair   (all pairs)
+//   edge   FP32:         max_i d.m_i <= 1    9 FMA per pair   (pairs that pass the cone)
+//   exact  FP64, the reference's own arithmetic (rtx::tri_hit)  (pairs that pass both)
+//
+// Cone operands arrive eight triangles at a time as 32 wave-uniform dwords, so the compiler
+// keeps them in SGPRs (two s_load_dwordx16, next batch requested while the current one is
+// evaluated) and feeds them to v_pk_mul_f32 / v_pk_fma_f32 as the scalar operand, two
+// triangles per instruction, the ray component broadcast by op_sel.  Steady state per
+// (ray, triangle): 1.5 packed FMA-class instructions and half a v_max3_f32; no LDS, no MFMA,
+// no cross-lane traffic.  When some lane's running maximum reaches 1 (or the batch is
+// flagged) the wave takes the rare path for that batch: per triangle, cone again (to find
+// which), then the edge test, then the FP64 decision for the nominated rays, in list order.
+// A ray that gets its hit is poisoned with NaN (it nominates nothing afterwards); the wave
+// leaves the loop once every one of its rays has a hit (list-order policy: the first hit is
+// final).
 //
 // mode 0: queue entries are sample ids awaiting the children of bounding object
 //         `obj_filter`; the result is written to hit_id[s] and hits are appended to q_shade.
 // mode 1: top-level runs; the result (triangle index or -1) goes to tri_hit[q].
 template <int R>
 __global__ void __launch_bounds__(256)
-k_search_primary(FrameConst fc, SceneDev sc, const int2* __restrict__ blocks, const int* __restrict__ queue,
-                 const int* __restrict__ nq_ptr, int mode, int obj_filter, const f2* __restrict__ filt,
-                 const int* __restrict__ npacked_ptr, const int* __restrict__ packed_tri, int* hit_id,
-                 int* tri_hit, int* q_shade, DevCounters* cnt) {
+k_search_primary(const FrameConst* __restrict__ fcp, SceneDev sc, const int* __restrict__ queue,
+                 const int* __restrict__ nq_ptr, int mode, int obj_filter, const f2* __restrict__ cone,
+                 const float* __restrict__ edge, const int* __restrict__ npacked_ptr,
+                 const int* __restrict__ packed_tri, const double* __restrict__ dirs, int* hit_id, int* tri_hit,
+                 int* q_shade, DevCounters* cnt) {
   const int nq = *nq_ptr;
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -466,97 +517,104 @@ k_search_primary(FrameConst fc, SceneDev sc, const int2* __restrict__ blocks, co
   unsigned long long n_exact = 0;
 
   int sid[R], best[R], upto[R];
-  bool valid[R];
   float dx[R], dy[R], dz[R];
   const float qnan = __builtin_nanf("");
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     int q = base + r * 64 + lane;
-    valid[r] = q < nq;
-    sid[r] = valid[r] ? queue[q] : -1;
+    bool valid = q < nq;
+    sid[r] = valid ? queue[q] : -1;
+    if (valid && mode == 0 && hit_id[sid[r]] != -2 - obj_filter) sid[r] = -1;
     best[r] = -1;
     upto[r] = 0;
-    if (valid[r] && mode == 0 && hit_id[sid[r]] != -2 - obj_filter) valid[r] = false;
     dx[r] = dy[r] = dz[r] = qnan;
-    if (valid[r]) {
-      int x, y, k;
-      sample_coords(fc, blocks, sid[r], &x, &y, &k);
-      d3 d = sample_dir(fc, x, y, k);
-      dx[r] = (float)d.x; dy[r] = (float)d.y; dz[r] = (float)d.z;
+    if (sid[r] >= 0) {
+      const double* dp = dirs + (size_t)sid[r] * 3;
+      dx[r] = (float)dp[0]; dy[r] = (float)dp[1]; dz[r] = (float)dp[2];
     }
   }
 
   int done_batches = nbatch;
   if (nbatch > 0) {
-    f2 cur[18];
+    f2 cur[12];
+    int flag = reinterpret_cast<const int*>(cone)[CONE_FLAG];
 #pragma unroll
-    for (int c = 0; c < 18; ++c) cur[c] = filt[c];
+    for (int c = 0; c < 12; ++c) cur[c] = cone[c];
     for (int b = 0; b < nbatch; ++b) {
-      f2 nxt[18];
-      const f2* p = filt + (size_t)(b + 1) * 18;  // one spare batch is allocated past the end
+      // request the next batch (one spare, zero-filled batch is allocated past the end)
+      f2 nxt[12];
+      const f2* np_ = cone + (size_t)(b + 1) * (CONE_DWORDS / 2);
 #pragma unroll
-      for (int c = 0; c < 18; ++c) nxt[c] = p[c];
+      for (int c = 0; c < 12; ++c) nxt[c] = np_[c];
+      int nflag = reinterpret_cast<const int*>(np_)[CONE_FLAG];
 
-      float mn = 3.0e38f;
+      float mx = -3.0e38f;
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
+      for (int pr = 0; pr < 4; ++pr) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           f2 X = {dx[r], dx[r]}, Y = {dy[r], dy[r]}, Z = {dz[r], dz[r]};
-          f2 s0 = __builtin_elementwise_fma(cur[h * 9 + 2], Z, __builtin_elementwise_fma(cur[h * 9 + 1], Y, cur[h * 9 + 0] * X));
-          f2 s1 = __builtin_elementwise_fma(cur[h * 9 + 5], Z, __builtin_elementwise_fma(cur[h * 9 + 4], Y, cur[h * 9 + 3] * X));
-          f2 s2 = __builtin_elementwise_fma(cur[h * 9 + 8], Z, __builtin_elementwise_fma(cur[h * 9 + 7], Y, cur[h * 9 + 6] * X));
-          float ma = __builtin_fmaxf(__builtin_fmaxf(s0.x, s1.x), s2.x);
-          float mb = __builtin_fmaxf(__builtin_fmaxf(s0.y, s1.y), s2.y);
-          mn = __builtin_fminf(__builtin_fminf(mn, ma), mb);
+          f2 q = __builtin_elementwise_fma(cur[pr * 3 + 2], Z, __builtin_elementwise_fma(cur[pr * 3 + 1], Y, cur[pr * 3 + 0] * X));
+          mx = __builtin_fmaxf(__builtin_fmaxf(mx, q.x), q.y);
         }
       }
 
-      if (__builtin_expect(__any(mn <= 1.0f), 0)) {
-        if (mn <= 1.0f) {
+      if (__builtin_expect(__any(mx >= 1.0f) || flag != 0, 0)) {
+        // ---- rare path: look closer at the eight triangles of this batch, in list order ----
+        for (int j = 0; j < TRI_BATCH; ++j) {
+          const int g = b * TRI_BATCH + j;
+          if (g >= npacked) break;
+          const float* wj = reinterpret_cast<const float*>(cone) + (size_t)b * CONE_DWORDS + (j >> 1) * 6 + (j & 1);
+          const float wx = wj[0], wy = wj[2], wz = wj[4];
+          unsigned nom = 0;  // bit r: ray r of this lane passes the cone of triangle j
 #pragma unroll
           for (int r = 0; r < R; ++r) {
-            if (best[r] >= 0 || !valid[r]) continue;
+            float q = __builtin_fmaf(wz, dz[r], __builtin_fmaf(wy, dy[r], wx * dx[r]));
+            // !(q < 1) also lets a NaN cone (wide triangle) through; finished or absent rays are excluded
+            if (!(q < 1.0f) && best[r] < 0 && sid[r] >= 0) nom |= 1u << r;
+          }
+          if (!__any(nom != 0)) continue;
+          const float* m = edge + (size_t)g * EDGE_FLOATS;
+          const float m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3], m4 = m[4], m5 = m[5], m6 = m[6], m7 = m[7], m8 = m[8];
 #pragma unroll
-            for (int j = 0; j < TRI_BATCH; ++j) {
-              if (best[r] >= 0) continue;
-              const int h = j >> 1;
-              float m[9];
+          for (int r = 0; r < R; ++r) {
+            float s0 = __builtin_fmaf(m2, dz[r], __builtin_fmaf(m1, dy[r], m0 * dx[r]));
+            float s1 = __builtin_fmaf(m5, dz[r], __builtin_fmaf(m4, dy[r], m3 * dx[r]));
+            float s2 = __builtin_fmaf(m8, dz[r], __builtin_fmaf(m7, dy[r], m6 * dx[r]));
+            float e = __builtin_fmaxf(__builtin_fmaxf(s0, s1), s2);
+            if (!(e <= 1.0f)) nom &= ~(1u << r);
+          }
+          if (!__any(nom != 0)) continue;
+          const int ti = packed_tri[g];
+          const rtmi_triangle& tr = sc.tris[ti];
+          const d3 v0 = rtx::ld3(tr.v[0]), v1 = rtx::ld3(tr.v[1]), v2 = rtx::ld3(tr.v[2]);
+          const TriPlane pl = sc.planes[ti];
+          const d3 cam = rtx::ld3(fcp->cam);
 #pragma unroll
-              for (int c = 0; c < 9; ++c) m[c] = (j & 1) ? cur[h * 9 + c].y : cur[h * 9 + c].x;
-              float s0 = __builtin_fmaf(m[2], dz[r], __builtin_fmaf(m[1], dy[r], m[0] * dx[r]));
-              float s1 = __builtin_fmaf(m[5], dz[r], __builtin_fmaf(m[4], dy[r], m[3] * dx[r]));
-              float s2 = __builtin_fmaf(m[8], dz[r], __builtin_fmaf(m[7], dy[r], m[6] * dx[r]));
-              float mx = __builtin_fmaxf(__builtin_fmaxf(s0, s1), s2);
-              if (mx <= 1.0f) {
-                int g = b * TRI_BATCH + j;
-                if (g < npacked) {
-                  int ti = packed_tri[g];
-                  int x, y, k;
-                  sample_coords(fc, blocks, sid[r], &x, &y, &k);
-                  d3 d = sample_dir(fc, x, y, k);
-                  const rtmi_triangle& tr = sc.tris[ti];
-                  double t;
-                  d3 P;
-                  n_exact += 1;
-                  if (rtx::tri_hit(rtx::ld3(tr.v[0]), rtx::ld3(tr.v[1]), rtx::ld3(tr.v[2]), sc.planes[ti],
-                                   rtx::ld3(fc.cam), d, &t, &P)) {
-                    best[r] = ti;
-                    upto[r] = g + 1;  // list positions this ray consumed
-                    dx[r] = dy[r] = dz[r] = qnan;
-                  }
-                }
+          for (int r = 0; r < R; ++r) {
+            if (!__any((nom >> r) & 1u)) continue;
+            if ((nom >> r) & 1u) {
+              const double* dp = dirs + (size_t)sid[r] * 3;
+              d3 d = rtx::mk(dp[0], dp[1], dp[2]);
+              double t;
+              d3 P;
+              n_exact += 1;
+              if (rtx::tri_hit(v0, v1, v2, pl, cam, d, &t, &P)) {
+                best[r] = ti;
+                upto[r] = g + 1;  // list positions this ray consumed
+                dx[r] = dy[r] = dz[r] = qnan;
               }
             }
           }
         }
         bool all_done = true;
 #pragma unroll
-        for (int r = 0; r < R; ++r) all_done = all_done && (best[r] >= 0 || !valid[r]);
+        for (int r = 0; r < R; ++r) all_done = all_done && (best[r] >= 0 || sid[r] < 0);
         if (__all(all_done)) { done_batches = b + 1; break; }
       }
 #pragma unroll
-      for (int c = 0; c < 18; ++c) cur[c] = nxt[c];
+      for (int c = 0; c < 12; ++c) cur[c] = nxt[c];
+      flag = nflag;
     }
   }
 
@@ -566,7 +624,7 @@ k_search_primary(FrameConst fc, SceneDev sc, const int2* __restrict__ blocks, co
   unsigned long long tests = 0;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    if (valid[r]) tests += best[r] >= 0 ? (unsigned long long)upto[r] : walked;
+    if (sid[r] >= 0) tests += best[r] >= 0 ? (unsigned long long)upto[r] : walked;
   }
   wave_count(cnt, C_TESTS_PRIMARY, tests);
   wave_count(cnt, C_EXACT, n_exact);
@@ -580,8 +638,8 @@ k_search_primary(FrameConst fc, SceneDev sc, const int2* __restrict__ blocks, co
     int wave_total = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      if (valid[r]) hit_id[sid[r]] = best[r];
-      masks[r] = __ballot(valid[r] && best[r] >= 0);
+      if (sid[r] >= 0) hit_id[sid[r]] = best[r];
+      masks[r] = __ballot(sid[r] >= 0 && best[r] >= 0);
       wave_total += __popcll(masks[r]);
     }
     if (lane == 0) wtot[w] = wave_total;
@@ -595,7 +653,7 @@ k_search_primary(FrameConst fc, SceneDev sc, const int2* __restrict__ blocks, co
     for (int q = 0; q < w; ++q) pos += wtot[q];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      if (valid[r] && best[r] >= 0) q_shade[pos + __popcll(masks[r] & ((1ull << lane) - 1ull))] = sid[r];
+      if (sid[r] >= 0 && best[r] >= 0) q_shade[pos + __popcll(masks[r] & ((1ull << lane) - 1ull))] = sid[r];
       pos += __popcll(masks[r]);
     }
   } else {
@@ -677,15 +735,13 @@ __device__ RGBd calculate_lighting(const SceneDev& sc, const FrameConst& fc, con
 }
 
 __global__ void __launch_bounds__(256)
-k_shade(FrameConst fc, SceneDev sc, const int2* __restrict__ blocks, const int* __restrict__ q_shade,
+k_shade(FrameConst fc, SceneDev sc, const double* __restrict__ dirs, const int* __restrict__ q_shade,
         const int* __restrict__ nq_ptr, const int* __restrict__ hit_id, double* rgb, DevCounters* cnt) {
   int q = blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long n_refl = 0, n_shadow = 0, n_hit = 0;
   if (q < *nq_ptr) {
     int s = q_shade[q];
-    int x, y, k;
-    sample_coords(fc, blocks, s, &x, &y, &k);
-    d3 d = sample_dir(fc, x, y, k);
+    d3 d = rtx::mk(dirs[(size_t)s * 3 + 0], dirs[(size_t)s * 3 + 1], dirs[(size_t)s * 3 + 2]);
     d3 cam = rtx::ld3(fc.cam);
     int id = hit_id[s];
     Hit h;
@@ -767,10 +823,11 @@ struct TriGroup {
   int* d_group = nullptr;       // ordinal -> triangle index
   unsigned char* d_keep = nullptr;
   int* d_block_counts = nullptr;
-  float* d_filt = nullptr;      // (n/4 + 2) batches of FILT_FLOATS
+  float* d_cone = nullptr;      // (n/8 + 2) batches of CONE_DWORDS
+  float* d_edge = nullptr;      // n x EDGE_FLOATS
   int* d_packed_tri = nullptr;
   int* d_npacked = nullptr;     // triangles kept by the last pack
-  size_t filt_bytes = 0;
+  size_t cone_bytes = 0;
 };
 
 struct rtmi_scene {
@@ -796,6 +853,9 @@ struct rtmi_scene {
   int* d_q_shade = nullptr;
   int* d_q_top = nullptr;
   double* d_rgb = nullptr;
+  double* d_dirs = nullptr;
+  FrameConst* d_fc = nullptr;
+  FrameConst h_fc{};
   int2* d_blocks = nullptr;
   size_t cap_blocks = 0;
   DevCounters* d_cnt = nullptr;
@@ -839,9 +899,10 @@ static int32_t alloc_group(TriGroup& g, const std::vector<int>& idx) {
   if (g.n) HIP_TRY(hipMemcpy(g.d_group, idx.data(), sizeof(int) * g.n, hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc(&g.d_keep, n1));
   HIP_TRY(hipMalloc(&g.d_block_counts, sizeof(int) * nblocks));
-  g.filt_bytes = sizeof(float) * FILT_FLOATS * ((size_t)(g.n + TRI_BATCH - 1) / TRI_BATCH + 2);
-  HIP_TRY(hipMalloc(&g.d_filt, g.filt_bytes));
-  HIP_TRY(hipMemset(g.d_filt, 0xFF, g.filt_bytes));
+  g.cone_bytes = sizeof(float) * CONE_DWORDS * ((size_t)(g.n + TRI_BATCH - 1) / TRI_BATCH + 2);
+  HIP_TRY(hipMalloc(&g.d_cone, g.cone_bytes));
+  HIP_TRY(hipMemset(g.d_cone, 0, g.cone_bytes));
+  HIP_TRY(hipMalloc(&g.d_edge, sizeof(float) * EDGE_FLOATS * n1));
   HIP_TRY(hipMalloc(&g.d_packed_tri, sizeof(int) * n1));
   HIP_TRY(hipMalloc(&g.d_npacked, sizeof(int)));
   HIP_TRY(hipMemset(g.d_npacked, 0, sizeof(int)));
@@ -907,12 +968,13 @@ extern "C" void rtmi_scene_destroy(rtmi_scene* sc) {
   if (sc->stream) (void)hipStreamSynchronize(sc->stream);
   for (auto& g : sc->groups) {
     (void)hipFree(g.d_group); (void)hipFree(g.d_keep); (void)hipFree(g.d_block_counts);
-    (void)hipFree(g.d_filt); (void)hipFree(g.d_packed_tri); (void)hipFree(g.d_npacked);
+    (void)hipFree(g.d_cone); (void)hipFree(g.d_edge); (void)hipFree(g.d_packed_tri); (void)hipFree(g.d_npacked);
   }
   (void)hipFree(sc->d_objects); (void)hipFree(sc->d_lights); (void)hipFree(sc->d_materials);
   (void)hipFree(sc->d_tris); (void)hipFree(sc->d_planes); (void)hipFree(sc->d_tri_owner);
   (void)hipFree(sc->d_hit_id); (void)hipFree(sc->d_tri_hit); (void)hipFree(sc->d_q_child);
   (void)hipFree(sc->d_q_shade); (void)hipFree(sc->d_q_top); (void)hipFree(sc->d_rgb);
+  (void)hipFree(sc->d_dirs); (void)hipFree(sc->d_fc);
   (void)hipFree(sc->d_blocks); (void)hipFree(sc->d_cnt);
   if (sc->ev_a) (void)hipEventDestroy(sc->ev_a);
   if (sc->ev_b) (void)hipEventDestroy(sc->ev_b);
@@ -1007,6 +1069,7 @@ static int32_t scene_create_impl(const rtmi_scene_desc* desc, int32_t device, rt
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipMalloc(&sc->d_cnt, sizeof(DevCounters)));
+  HIP_TRY(hipMalloc(&sc->d_fc, sizeof(FrameConst)));
   HIP_TRY(hipStreamSynchronize(sc->stream));
 
   sc->dev.objects = sc->d_objects;
@@ -1041,8 +1104,9 @@ static int32_t ensure_buffers(rtmi_scene* sc, size_t samples, size_t blocks) {
   if (samples > sc->cap_samples) {
     (void)hipFree(sc->d_hit_id); (void)hipFree(sc->d_tri_hit); (void)hipFree(sc->d_q_child);
     (void)hipFree(sc->d_q_shade); (void)hipFree(sc->d_q_top); (void)hipFree(sc->d_rgb);
+    (void)hipFree(sc->d_dirs);
     sc->d_hit_id = sc->d_tri_hit = sc->d_q_child = sc->d_q_shade = sc->d_q_top = nullptr;
-    sc->d_rgb = nullptr;
+    sc->d_rgb = sc->d_dirs = nullptr;
     sc->cap_samples = 0;
     HIP_TRY(hipMalloc(&sc->d_hit_id, sizeof(int) * samples));
     HIP_TRY(hipMalloc(&sc->d_tri_hit, sizeof(int) * samples));
@@ -1050,6 +1114,7 @@ static int32_t ensure_buffers(rtmi_scene* sc, size_t samples, size_t blocks) {
     HIP_TRY(hipMalloc(&sc->d_q_shade, sizeof(int) * samples));
     HIP_TRY(hipMalloc(&sc->d_q_top, sizeof(int) * samples));
     HIP_TRY(hipMalloc(&sc->d_rgb, sizeof(double) * 3 * samples));
+    HIP_TRY(hipMalloc(&sc->d_dirs, sizeof(double) * 3 * samples));
     sc->cap_samples = samples;
   }
   if (blocks > sc->cap_blocks) {
@@ -1066,12 +1131,12 @@ static int32_t ensure_buffers(rtmi_scene* sc, size_t samples, size_t blocks) {
 static int32_t pack_group(rtmi_scene* sc, TriGroup& g, d3 cam) {
   if (g.n == 0) return RTMI_OK;
   int nblocks = (g.n + 255) / 256;
-  HIP_TRY(hipMemsetAsync(g.d_filt, 0xFF, g.filt_bytes, sc->stream));  // all-ones = NaN: never nominates
+  HIP_TRY(hipMemsetAsync(g.d_cone, 0, g.cone_bytes, sc->stream));  // zero cone vector: never nominates; flags clear
   hipLaunchKernelGGL(k_pack_flags, dim3(nblocks), dim3(256), 0, sc->stream, sc->d_tris, sc->d_planes, g.d_group, g.n,
                      cam, g.d_keep, g.d_block_counts);
   hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(1024), 0, sc->stream, g.d_block_counts, nblocks, g.d_npacked);
   hipLaunchKernelGGL(k_pack_write, dim3(nblocks), dim3(256), 0, sc->stream, sc->d_tris, g.d_group, g.n, cam, g.d_keep,
-                     g.d_block_counts, g.d_filt, g.d_packed_tri);
+                     g.d_block_counts, g.d_cone, g.d_edge, g.d_packed_tri);
   HIP_TRY(hipGetLastError());
   return RTMI_OK;
 }
@@ -1163,6 +1228,8 @@ static int32_t render_impl(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_pa
   hipStream_t st = sc->stream;
   HIP_TRY(hipEventRecord(sc->ev_a, st));
   HIP_TRY(hipMemsetAsync(sc->d_cnt, 0, sizeof(DevCounters), st));
+  sc->h_fc = fc;  // lives in the scene object: the async copy may read it after this statement
+  HIP_TRY(hipMemcpyAsync(sc->d_fc, &sc->h_fc, sizeof(FrameConst), hipMemcpyHostToDevice, st));
   if (!blocks.empty())
     HIP_TRY(hipMemcpyAsync(sc->d_blocks, blocks.data(), sizeof(int2) * blocks.size(), hipMemcpyHostToDevice, st));
 
@@ -1180,7 +1247,7 @@ static int32_t render_impl(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_pa
     const int2* d_blk = sc->d_blocks + b0;
     HIP_TRY(hipMemsetAsync(&sc->d_cnt->q_child, 0, sizeof(int) * 3, st));
     int grid = (nsamples + 255) / 256;
-    hipLaunchKernelGGL(k_gen, dim3((nsamples + 256 * GEN_ITERS - 1) / (256 * GEN_ITERS)), dim3(256), 0, st, fc, sc->dev, d_blk, nsamples, sc->d_hit_id, sc->d_q_child,
+    hipLaunchKernelGGL(k_gen, dim3((nsamples + 256 * GEN_ITERS - 1) / (256 * GEN_ITERS)), dim3(256), 0, st, fc, sc->dev, d_blk, nsamples, sc->d_hit_id, sc->d_dirs, sc->d_q_child,
                        sc->d_q_shade, sc->d_q_top, sc->d_cnt);
     const int search_grid = (nsamples + 256 * SEARCH_R - 1) / (256 * SEARCH_R);
     if (sc->groups[0].n > 0) {
@@ -1188,9 +1255,9 @@ static int32_t render_impl(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_pa
       hipEvent_t e0, e1;
       HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
       HIP_TRY(hipEventRecord(e0, st));
-      hipLaunchKernelGGL(k_search_primary<SEARCH_R>, dim3(search_grid), dim3(256), 0, st, fc, sc->dev, d_blk, sc->d_q_top,
-                         &sc->d_cnt->q_top, 1, -1, (const f2*)g.d_filt, g.d_npacked, g.d_packed_tri,
-                         sc->d_hit_id, sc->d_tri_hit, sc->d_q_shade, sc->d_cnt);
+      hipLaunchKernelGGL(k_search_primary<SEARCH_R>, dim3(search_grid), dim3(256), 0, st, sc->d_fc, sc->dev, sc->d_q_top,
+                         &sc->d_cnt->q_top, 1, -1, (const f2*)g.d_cone, g.d_edge, g.d_npacked, g.d_packed_tri,
+                         sc->d_dirs, sc->d_hit_id, sc->d_tri_hit, sc->d_q_shade, sc->d_cnt);
       HIP_TRY(hipEventRecord(e1, st));
       timed.emplace_back(e0, e1);
       ++launches;
@@ -1202,14 +1269,14 @@ static int32_t render_impl(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_pa
       hipEvent_t e0, e1;
       HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
       HIP_TRY(hipEventRecord(e0, st));
-      hipLaunchKernelGGL(k_search_primary<SEARCH_R>, dim3(search_grid), dim3(256), 0, st, fc, sc->dev, d_blk, sc->d_q_child,
-                         &sc->d_cnt->q_child, 0, g.object, (const f2*)g.d_filt, g.d_npacked, g.d_packed_tri,
-                         sc->d_hit_id, sc->d_tri_hit, sc->d_q_shade, sc->d_cnt);
+      hipLaunchKernelGGL(k_search_primary<SEARCH_R>, dim3(search_grid), dim3(256), 0, st, sc->d_fc, sc->dev, sc->d_q_child,
+                         &sc->d_cnt->q_child, 0, g.object, (const f2*)g.d_cone, g.d_edge, g.d_npacked, g.d_packed_tri,
+                         sc->d_dirs, sc->d_hit_id, sc->d_tri_hit, sc->d_q_shade, sc->d_cnt);
       HIP_TRY(hipEventRecord(e1, st));
       timed.emplace_back(e0, e1);
       ++launches;
     }
-    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(256), 0, st, fc, sc->dev, d_blk, sc->d_q_shade, &sc->d_cnt->q_shade,
+    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(256), 0, st, fc, sc->dev, sc->d_dirs, sc->d_q_shade, &sc->d_cnt->q_shade,
                        sc->d_hit_id, sc->d_rgb, sc->d_cnt);
     int npix = (int)(nb * BLK_PIX);
     hipLaunchKernelGGL(k_resolve, dim3((npix + 255) / 256), dim3(256), 0, st, fc, d_blk, npix, sc->d_hit_id, sc->d_rgb,
