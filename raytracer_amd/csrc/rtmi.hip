@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -64,6 +65,9 @@ struct FrameConst {
   double ambient[3];
   int W, H, x0, y0, x1, y1;
   int spp, n1;  // samples per pixel = n1*n1 (WorldCoordinateSequence.swift:74-78)
+  float inv_spp;
+  const double* utab;  // per sample column: (u * i) / pixelsPerWorldHorizontal
+  const double* vtab;  // per sample row:    (v * j) / pixelsPerWorldVertical
   int tile_size, tiles_x, tile_rank, tile_world;
 };
 
@@ -88,14 +92,9 @@ struct SceneDev {
   long long n_top_tris;
 };
 
-// sample index within a batch -> pixel and sub-sample; false if the pixel is not rendered
-__device__ inline bool sample_coords(const FrameConst& fc, const int2* __restrict__ blocks, int s,
-                                     int* x, int* y, int* k) {
-  int per_block = BLK_PIX * fc.spp;
-  int b = s / per_block;
-  int rem = s - b * per_block;
-  int pix = rem / fc.spp;
-  *k = rem - pix * fc.spp;
+// Pixel `pix` (0..63, row-major in the 8x8 block) of block `b`; false if it is not rendered.
+__device__ inline bool pixel_coords(const FrameConst& fc, const int2* __restrict__ blocks, int b, int pix,
+                                    int* x, int* y) {
   int2 bc = blocks[b];
   int px = bc.x * BLK + (pix & (BLK - 1));
   int py = bc.y * BLK + (pix >> 3);
@@ -109,14 +108,49 @@ __device__ inline bool sample_coords(const FrameConst& fc, const int2* __restric
   return true;
 }
 
+// Sample index within a batch -> pixel and sub-sample.  s = ((b*spp + k) << 6) + pix: the 64
+// lanes of a wave are the 64 pixels of one 8x8 block at the same sub-sample, so per-sample
+// arrays are read and written coalesced by k_gen, k_search_primary and k_resolve alike.
+__device__ inline bool sample_coords(const FrameConst& fc, const int2* __restrict__ blocks, int s,
+                                     int* x, int* y, int* k) {
+  int pix = s & (BLK_PIX - 1);
+  int t = s >> 6;
+  int b = (int)((float)t * fc.inv_spp);  // t / spp for t < 2^22, corrected below
+  int rem = t - b * fc.spp;
+  if (rem < 0) { --b; rem += fc.spp; }
+  if (rem >= fc.spp) { ++b; rem -= fc.spp; }
+  *k = rem;
+  return pixel_coords(fc, blocks, b, pix, x, y);
+}
+
 // Primary ray direction of sample k of pixel (x, y): WorldCoordinateSequence.swift:62-78 and
-// RayTracingFunctions.swift:73.
+// RayTracingFunctions.swift:73.  The two quotients of pixelToWorldCoordinate depend only on the
+// sample's column and row; k_frame_tables evaluates them once per frame.
 __device__ inline d3 sample_dir(const FrameConst& fc, int x, int y, int k) {
   int kx = k / fc.n1, ky = k - kx * fc.n1;  // x outer, y inner
-  double i = fma((double)kx, fc.sub, (double)x);  // stride(from:to:by:) = start.addingProduct(k, by)
-  double j = fma((double)ky, fc.sub, (double)y);
-  d3 p = rtx::pixel_to_world(rtx::ld3(fc.ul), rtx::ld3(fc.u), rtx::ld3(fc.v), fc.ppw_h, fc.ppw_v, i, j);
+  const double* uc = fc.utab + (size_t)(x * fc.n1 + kx) * 3;
+  const double* vc = fc.vtab + (size_t)(y * fc.n1 + ky) * 3;
+  d3 p = rtx::sub(rtx::add(rtx::ld3(fc.ul), rtx::ld3(uc)), rtx::ld3(vc));  // ul + uComponent - vComponent
   return rtx::normalize(rtx::sub(p, rtx::ld3(fc.cam)));
+}
+
+// uComponent = (u * i) / pixelsPerWorldHorizontal for every sample column i = x + kx*sub, and
+// vComponent = (v * j) / pixelsPerWorldVertical for every sample row (WCS:63-64, :74-75).
+__global__ void k_frame_tables(FrameConst fc, double* utab, double* vtab) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int nu = fc.W * fc.n1, nv = fc.H * fc.n1;
+  if (i < nu) {
+    int x = i / fc.n1, kx = i - x * fc.n1;
+    double c = fma((double)kx, fc.sub, (double)x);  // stride(from:to:by:) = start.addingProduct(k, by)
+    d3 r = rtx::divs(rtx::muls(rtx::ld3(fc.u), c), fc.ppw_h);
+    utab[(size_t)i * 3 + 0] = r.x; utab[(size_t)i * 3 + 1] = r.y; utab[(size_t)i * 3 + 2] = r.z;
+  } else if (i < nu + nv) {
+    int j = i - nu;
+    int y = j / fc.n1, ky = j - y * fc.n1;
+    double c = fma((double)ky, fc.sub, (double)y);
+    d3 r = rtx::divs(rtx::muls(rtx::ld3(fc.v), c), fc.ppw_v);
+    vtab[(size_t)j * 3 + 0] = r.x; vtab[(size_t)j * 3 + 1] = r.y; vtab[(size_t)j * 3 + 2] = r.z;
+  }
 }
 
 // Sum v over the wave and add it to this wave's stripe of counter `idx`.
@@ -413,14 +447,16 @@ k_gen(FrameConst fc, SceneDev sc, const int2* __restrict__ blocks, int nsamples,
     bool to_child = false, to_shade = false;
     if (live) {
       d3 d = sample_dir(fc, x, y, k);
-      dirs[(size_t)s * 3 + 0] = d.x;  // kept for the FP64 decisions of the search and for shading
-      dirs[(size_t)s * 3 + 1] = d.y;
-      dirs[(size_t)s * 3 + 2] = d.z;
       Hit h;
       int obj = first_sphere_like(sc, rtx::ld3(fc.cam), d, &h);
       if (obj >= 0) {
         id = -2 - obj;
         if (sc.objects[obj].kind == RTMI_BOUNDING_SPHERE) to_child = true; else to_shade = true;
+      }
+      if (obj >= 0 || has_top) {  // kept for the FP64 decisions of the search and for shading
+        dirs[(size_t)s * 3 + 0] = d.x;
+        dirs[(size_t)s * 3 + 1] = d.y;
+        dirs[(size_t)s * 3 + 2] = d.z;
       }
     }
     if (s < nsamples) hit_id[s] = id;
@@ -548,16 +584,26 @@ k_search_primary(const FrameConst* __restrict__ fcp, SceneDev sc, const int* __r
       for (int c = 0; c < 12; ++c) nxt[c] = np_[c];
       int nflag = reinterpret_cast<const int*>(np_)[CONE_FLAG];
 
-      float mx = -3.0e38f;
+      // R independent chains per triangle pair so that consecutive instructions do not depend
+      // on each other
+      float mxr[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) mxr[r] = -3.0e38f;
 #pragma unroll
       for (int pr = 0; pr < 4; ++pr) {
+        f2 q[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-          f2 X = {dx[r], dx[r]}, Y = {dy[r], dy[r]}, Z = {dz[r], dz[r]};
-          f2 q = __builtin_elementwise_fma(cur[pr * 3 + 2], Z, __builtin_elementwise_fma(cur[pr * 3 + 1], Y, cur[pr * 3 + 0] * X));
-          mx = __builtin_fmaxf(__builtin_fmaxf(mx, q.x), q.y);
-        }
+        for (int r = 0; r < R; ++r) { f2 X = {dx[r], dx[r]}; q[r] = cur[pr * 3 + 0] * X; }
+#pragma unroll
+        for (int r = 0; r < R; ++r) { f2 Y = {dy[r], dy[r]}; q[r] = __builtin_elementwise_fma(cur[pr * 3 + 1], Y, q[r]); }
+#pragma unroll
+        for (int r = 0; r < R; ++r) { f2 Z = {dz[r], dz[r]}; q[r] = __builtin_elementwise_fma(cur[pr * 3 + 2], Z, q[r]); }
+#pragma unroll
+        for (int r = 0; r < R; ++r) mxr[r] = __builtin_fmaxf(__builtin_fmaxf(mxr[r], q[r].x), q[r].y);
       }
+      float mx = mxr[0];
+#pragma unroll
+      for (int r = 1; r < R; ++r) mx = __builtin_fmaxf(mx, mxr[r]);
 
       if (__builtin_expect(__any(mx >= 1.0f) || flag != 0, 0)) {
         // ---- rare path: look closer at the eight triangles of this batch, in list order ----
@@ -672,6 +718,25 @@ struct RGBd {
   double r, g, b;
 };
 
+// pow(base, exponent) of the specular term (RayTracingFunctions.swift:259), base in (0, 1].
+// For the usual small whole-number exponents (OBJ "Ns" values like 8) binary powering is used:
+// at most ceil(log2 n)+popcount roundings, i.e. a few ulp, far below what can change
+// UInt8(255 * c); every other exponent goes through the device pow().
+__device__ inline double spec_pow(double base, double e) {
+  if (e >= 1.0 && e <= 64.0 && e == floor(e)) {
+    int n = (int)e;
+    double r = 1.0, b = base;
+    bool first = true;
+    while (n) {
+      if (n & 1) { r = first ? b : r * b; first = false; }
+      n >>= 1;
+      if (n) b = b * b;
+    }
+    return r;
+  }
+  return pow(base, e);
+}
+
 template <bool REFLECT>
 __device__ RGBd calculate_lighting(const SceneDev& sc, const FrameConst& fc, const Hit& is, d3 camera,
                                    unsigned long long* n_refl, unsigned long long* n_shadow) {
@@ -723,7 +788,7 @@ __device__ RGBd calculate_lighting(const SceneDev& sc, const FrameConst& fc, con
     d3 light_reflection = rtx::normalize(rtx::sub(rtx::smul(2 * ndl, normal), point_to_light));  // RTF:251
     double rv = rtx::dp(light_reflection, surface_to_camera);
     if (rv <= 0) continue;  // RTF:255-257
-    double specular_term = pow(rv, mat.Ns);  // RTF:259
+    double specular_term = spec_pow(rv, mat.Ns);  // RTF:259
     double sr = light.specular[0], sg = light.specular[1], sb = light.specular[2];
     sr = specular_term * sr; sg = specular_term * sg; sb = specular_term * sb;
     sr = mat.Ks[0] * sr; sg = mat.Ks[1] * sg; sb = mat.Ks[2] * sb;
@@ -790,28 +855,28 @@ k_resolve(FrameConst fc, const int2* __restrict__ blocks, int npix, const int* _
           const double* __restrict__ rgb, unsigned char* rgba, int* hit_out) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= npix) return;
-  int s0 = p * fc.spp;
-  int x, y, k;
-  if (!sample_coords(fc, blocks, s0, &x, &y, &k)) return;
-  double cr = 0.0, cg = 0.0, cb = 0.0;
+  int b = p >> 6, pix = p & (BLK_PIX - 1);
+  int x, y;
+  if (!pixel_coords(fc, blocks, b, pix, &x, &y)) return;
+  double cr = 0.0, cg = 0.0, cb = 0.0;  // cumulative = RGB(0,0,0), Utilities.swift:56
   for (int q = 0; q < fc.spp; ++q) {
-    int id = hit_id[s0 + q];
-    double r = 0.0, g = 0.0, b = 0.0;
+    int s = ((b * fc.spp + q) << 6) + pix;
+    int id = hit_id[s];
+    double r = 0.0, g = 0.0, bl = 0.0;  // RGB.black for a miss
     if (id != -1) {
-      r = rgb[(size_t)(s0 + q) * 3 + 0];
-      g = rgb[(size_t)(s0 + q) * 3 + 1];
-      b = rgb[(size_t)(s0 + q) * 3 + 2];
+      r = rgb[(size_t)s * 3 + 0];
+      g = rgb[(size_t)s * 3 + 1];
+      bl = rgb[(size_t)s * 3 + 2];
     }
-    cr = cr + r; cg = cg + g; cb = cb + b;
+    cr = cr + r; cg = cg + g; cb = cb + bl;
     if (hit_out) hit_out[((size_t)y * fc.W + x) * fc.spp + q] = id;
   }
-  double factor = 1 / (double)fc.spp;
+  double factor = 1 / (double)fc.spp;  // Utilities.swift:61-62
   double ar = factor * cr, ag = factor * cg, ab = factor * cb;
-  size_t first_byte = (size_t)4 * fc.W * y + (size_t)x * 4;
-  rgba[first_byte] = (unsigned char)(255 * ar);
-  rgba[first_byte + 1] = (unsigned char)(255 * ag);
-  rgba[first_byte + 2] = (unsigned char)(255 * ab);
-  rgba[first_byte + 3] = 255;
+  size_t first_byte = (size_t)4 * fc.W * y + (size_t)x * 4;  // RayTracingFunctions.swift:106-107
+  unsigned int px = (unsigned int)(unsigned char)(255 * ar) | ((unsigned int)(unsigned char)(255 * ag) << 8) |
+                    ((unsigned int)(unsigned char)(255 * ab) << 16) | (255u << 24);
+  *reinterpret_cast<unsigned int*>(rgba + first_byte) = px;  // R,G,B,255 in memory order (:108-111)
 }
 
 // ---------------------------------------------------------------------------------------
@@ -856,6 +921,8 @@ struct rtmi_scene {
   double* d_dirs = nullptr;
   FrameConst* d_fc = nullptr;
   FrameConst h_fc{};
+  double* d_tabs = nullptr;  // utab then vtab
+  size_t cap_tabs = 0;
   int2* d_blocks = nullptr;
   size_t cap_blocks = 0;
   DevCounters* d_cnt = nullptr;
@@ -974,7 +1041,7 @@ extern "C" void rtmi_scene_destroy(rtmi_scene* sc) {
   (void)hipFree(sc->d_tris); (void)hipFree(sc->d_planes); (void)hipFree(sc->d_tri_owner);
   (void)hipFree(sc->d_hit_id); (void)hipFree(sc->d_tri_hit); (void)hipFree(sc->d_q_child);
   (void)hipFree(sc->d_q_shade); (void)hipFree(sc->d_q_top); (void)hipFree(sc->d_rgb);
-  (void)hipFree(sc->d_dirs); (void)hipFree(sc->d_fc);
+  (void)hipFree(sc->d_dirs); (void)hipFree(sc->d_fc); (void)hipFree(sc->d_tabs);
   (void)hipFree(sc->d_blocks); (void)hipFree(sc->d_cnt);
   if (sc->ev_a) (void)hipEventDestroy(sc->ev_a);
   if (sc->ev_b) (void)hipEventDestroy(sc->ev_b);
@@ -1141,8 +1208,16 @@ static int32_t pack_group(rtmi_scene* sc, TriGroup& g, d3 cam) {
   return RTMI_OK;
 }
 
-constexpr int SEARCH_R = 4;
-constexpr size_t MAX_BATCH_SAMPLES = 1u << 25;  // 32 Mi samples per batch (about 1.2 GB of work buffers)
+static int search_rays_per_lane() {
+  // rays per lane of k_search_primary; RTMI_SEARCH_R=4|8 overrides the default for experiments
+  static int r = [] {
+    const char* e = getenv("RTMI_SEARCH_R");
+    int v = e ? atoi(e) : 4;
+    return v == 8 ? 8 : 4;
+  }();
+  return r;
+}
+constexpr size_t MAX_BATCH_SAMPLES = 1u << 28;  // 256 Mi samples per batch (68 B of work buffers per sample)
 
 static int32_t render_impl(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_params* p, void* rgba_dev,
                            void* hit_dev, rtmi_counters* counters) {
@@ -1190,6 +1265,19 @@ static int32_t render_impl(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_pa
   fc.tiles_x = p->tile_size > 0 ? (p->width - 1 + p->tile_size - 1) / p->tile_size : 1;
   fc.tile_rank = p->tile_rank;
   fc.tile_world = p->tile_world > 1 ? p->tile_world : 1;
+  fc.inv_spp = 1.0f / (float)spp;
+  {
+    size_t need = (size_t)(p->width + p->height) * n1 * 3;
+    if (need > sc->cap_tabs) {
+      (void)hipFree(sc->d_tabs);
+      sc->d_tabs = nullptr;
+      sc->cap_tabs = 0;
+      HIP_TRY(hipMalloc(&sc->d_tabs, sizeof(double) * need));
+      sc->cap_tabs = need;
+    }
+    fc.utab = sc->d_tabs;
+    fc.vtab = sc->d_tabs + (size_t)p->width * n1 * 3;
+  }
 
   // 8x8 pixel blocks that contain at least one pixel to render
   std::vector<int2> blocks;
@@ -1233,6 +1321,11 @@ static int32_t render_impl(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_pa
   if (!blocks.empty())
     HIP_TRY(hipMemcpyAsync(sc->d_blocks, blocks.data(), sizeof(int2) * blocks.size(), hipMemcpyHostToDevice, st));
 
+  {
+    int ntab = (p->width + p->height) * n1;
+    hipLaunchKernelGGL(k_frame_tables, dim3((ntab + 255) / 256), dim3(256), 0, st, fc, sc->d_tabs,
+                       sc->d_tabs + (size_t)p->width * n1 * 3);
+  }
   d3 camera = rtx::ld3(cam->pos);
   for (auto& g : sc->groups)
     if ((rc = pack_group(sc, g, camera))) return rc;
@@ -1249,13 +1342,15 @@ static int32_t render_impl(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_pa
     int grid = (nsamples + 255) / 256;
     hipLaunchKernelGGL(k_gen, dim3((nsamples + 256 * GEN_ITERS - 1) / (256 * GEN_ITERS)), dim3(256), 0, st, fc, sc->dev, d_blk, nsamples, sc->d_hit_id, sc->d_dirs, sc->d_q_child,
                        sc->d_q_shade, sc->d_q_top, sc->d_cnt);
-    const int search_grid = (nsamples + 256 * SEARCH_R - 1) / (256 * SEARCH_R);
+    const int SR = search_rays_per_lane();
+    const int search_grid = (nsamples + 256 * SR - 1) / (256 * SR);
+    auto search_kernel = SR == 8 ? k_search_primary<8> : k_search_primary<4>;
     if (sc->groups[0].n > 0) {
       TriGroup& g = sc->groups[0];
       hipEvent_t e0, e1;
       HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
       HIP_TRY(hipEventRecord(e0, st));
-      hipLaunchKernelGGL(k_search_primary<SEARCH_R>, dim3(search_grid), dim3(256), 0, st, sc->d_fc, sc->dev, sc->d_q_top,
+      hipLaunchKernelGGL(search_kernel, dim3(search_grid), dim3(256), 0, st, sc->d_fc, sc->dev, sc->d_q_top,
                          &sc->d_cnt->q_top, 1, -1, (const f2*)g.d_cone, g.d_edge, g.d_npacked, g.d_packed_tri,
                          sc->d_dirs, sc->d_hit_id, sc->d_tri_hit, sc->d_q_shade, sc->d_cnt);
       HIP_TRY(hipEventRecord(e1, st));
@@ -1269,7 +1364,7 @@ static int32_t render_impl(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_pa
       hipEvent_t e0, e1;
       HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
       HIP_TRY(hipEventRecord(e0, st));
-      hipLaunchKernelGGL(k_search_primary<SEARCH_R>, dim3(search_grid), dim3(256), 0, st, sc->d_fc, sc->dev, sc->d_q_child,
+      hipLaunchKernelGGL(search_kernel, dim3(search_grid), dim3(256), 0, st, sc->d_fc, sc->dev, sc->d_q_child,
                          &sc->d_cnt->q_child, 0, g.object, (const f2*)g.d_cone, g.d_edge, g.d_npacked, g.d_packed_tri,
                          sc->d_dirs, sc->d_hit_id, sc->d_tri_hit, sc->d_q_shade, sc->d_cnt);
       HIP_TRY(hipEventRecord(e1, st));
