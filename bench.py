@@ -6,7 +6,8 @@ displaced icosphere wrapped in Sphere(boundingObjects:), i.e. form B, what the r
 loadObjFile builds), 3840x2160, 16 samples per pixel (pixelSubdivision 0.25), 3 lights, shadow and
 reflection rays, reference-exact list-order hit policy.  With N > 1 the frame's 32x32 tiles are
 dealt cyclically over the ranks (strong scaling: total work per step is fixed), the scene is
-broadcast once over RCCL before the timed region and the RGBA8 frame is reduced to rank 0 inside it.
+broadcast once over RCCL before the timed region and every rank's own pixels are gathered on rank 0
+inside it.
 
 Prints ONE JSON line on rank 0.
 """
@@ -41,6 +42,11 @@ def main():
     ap.add_argument("--orbit", action="store_true", help="config 5: move the camera every step")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--verify", action="store_true",
+                    help="after timing, rank 0 re-renders the last frame alone and compares it byte for byte")
+    ap.add_argument("--rehearse-gloo", action="store_true",
+                    help="multi-rank logic check on a box with ONE GPU: all ranks render on device 0 and the "
+                         "collectives run over gloo on host tensors (not a performance mode)")
     args = ap.parse_args()
 
     import numpy as np
@@ -56,22 +62,29 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    if args.rehearse_gloo:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    comm_dev = torch.device("cpu") if args.rehearse_gloo else dev
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.rehearse_gloo:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     W, H, sub, level, n_lights = CONFIGS[args.config]
     data = None
     if rank == 0:
         data = scenes.mesh_scene(level, args.form, n_lights, bounding_sphere=rt.bounding_sphere)
     if world > 1:
-        data = sharding.broadcast_scene(data, 0, device=dev)  # RCCL byte broadcast, once
+        data = sharding.broadcast_scene(data, 0, device=comm_dev)  # RCCL byte broadcast, once
     scene = rt.Scene(data, device=local_rank)
     params = scenes.make_params(W, H, sub)
     my_params = sharding.tile_params(params, rank, world) if world > 1 else params
-    frame = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
+    composer = sharding.TileComposer(W, H, rank, world, comm_dev)
+    frame = composer.frame if not args.rehearse_gloo else torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
 
     def camera_for(step):
@@ -83,12 +96,10 @@ def main():
               "exact": 0, "samples": 0}
 
     def step(i, record):
-        if world > 1:
-            frame.zero_()
-            torch.cuda.current_stream().synchronize()
         cnt = scene.render_device(camera_for(i), my_params, frame.data_ptr())
-        if world > 1:
-            sharding.composite(frame, 0)
+        if args.rehearse_gloo:
+            composer.frame.copy_(frame)
+        composer.compose()  # rank 0 ends the step holding the whole frame
         if record:
             totals["rays"] += cnt["samples"] + cnt["rays_reflection"] + cnt["rays_shadow"]
             totals["samples"] += cnt["samples"]
@@ -115,7 +126,15 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
 
-    agg = torch.tensor([float(totals["rays"]), float(totals["tests"]), elapsed], dtype=torch.float64, device=dev)
+    verified = None
+    if args.verify and rank == 0:
+        alone = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        scene.render_device(camera_for(args.warmup + args.steps - 1), params, alone.data_ptr())
+        verified = bool((alone.cpu() == composer.frame.cpu()).all())
+        assert verified, "the composed multi-rank frame differs from the single-GPU frame"
+
+    agg = torch.tensor([float(totals["rays"]), float(totals["tests"]), elapsed], dtype=torch.float64, device=comm_dev)
     if world > 1:
         sums = agg.clone()
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)
@@ -150,8 +169,9 @@ def main():
                             f"form {args.form} ({'bounded by Sphere(boundingObjects:)' if args.form == 'B' else 'top-level triangles'}), "
                             "list-order hit policy" + (", orbiting camera" if args.orbit else ""),
                 "mesh": "stand-in (no pig OBJ available offline)",
-                "tiles": "32x32 cyclic over ranks" if world > 1 else "single GPU, whole frame",
+                "tiles": "32x32 cyclic over ranks, own pixels gathered on rank 0" if world > 1 else "single GPU, whole frame",
             },
+            "verified_against_single_gpu_frame": verified,
             "rays_per_step": int(total_rays / args.steps),
             "tests_per_s": tests_per_s,
             "tests_per_s_frac_of_fp32_roofline": tests_per_s * FLOPS_PER_TEST / (PEAK_FP32_TFLOPS * 1e12 * world),

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -925,6 +926,9 @@ struct rtmi_scene {
   size_t cap_tabs = 0;
   int2* d_blocks = nullptr;
   size_t cap_blocks = 0;
+  std::vector<int2> h_blocks;          // host copy of the block list last uploaded
+  std::array<int, 9> blocks_key{};     // frame geometry + tile selection it was built for
+  bool blocks_valid = false;
   DevCounters* d_cnt = nullptr;
   std::mutex mu;
 };
@@ -1188,6 +1192,7 @@ static int32_t ensure_buffers(rtmi_scene* sc, size_t samples, size_t blocks) {
     (void)hipFree(sc->d_blocks);
     sc->d_blocks = nullptr;
     sc->cap_blocks = 0;
+    sc->blocks_valid = false;
     HIP_TRY(hipMalloc(&sc->d_blocks, sizeof(int2) * blocks));
     sc->cap_blocks = blocks;
   }
@@ -1279,9 +1284,14 @@ static int32_t render_impl(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_pa
     fc.vtab = sc->d_tabs + (size_t)p->width * n1 * 3;
   }
 
-  // 8x8 pixel blocks that contain at least one pixel to render
-  std::vector<int2> blocks;
-  {
+  // 8x8 pixel blocks that contain at least one pixel to render.  The list depends only on the
+  // frame geometry and tile selection, so it is rebuilt (and re-uploaded) only when those change.
+  const std::array<int, 9> blocks_key = {p->width, p->height, x0, y0, x1, y1, fc.tile_size, fc.tile_rank, fc.tile_world};
+  const bool blocks_cached = sc->blocks_valid && sc->blocks_key == blocks_key;
+  std::vector<int2>& blocks = sc->h_blocks;
+  if (!blocks_cached) {
+    blocks.clear();
+    sc->blocks_valid = false;
     const bool tiled = fc.tile_world > 1;
     const bool aligned = tiled && (fc.tile_size % BLK == 0);
     for (int by = y0 / BLK; by * BLK < y1; ++by)
@@ -1318,8 +1328,12 @@ static int32_t render_impl(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_pa
   HIP_TRY(hipMemsetAsync(sc->d_cnt, 0, sizeof(DevCounters), st));
   sc->h_fc = fc;  // lives in the scene object: the async copy may read it after this statement
   HIP_TRY(hipMemcpyAsync(sc->d_fc, &sc->h_fc, sizeof(FrameConst), hipMemcpyHostToDevice, st));
-  if (!blocks.empty())
-    HIP_TRY(hipMemcpyAsync(sc->d_blocks, blocks.data(), sizeof(int2) * blocks.size(), hipMemcpyHostToDevice, st));
+  if (!blocks_cached || !sc->blocks_valid) {
+    if (!blocks.empty())
+      HIP_TRY(hipMemcpyAsync(sc->d_blocks, blocks.data(), sizeof(int2) * blocks.size(), hipMemcpyHostToDevice, st));
+    sc->blocks_key = blocks_key;
+    sc->blocks_valid = true;
+  }
 
   {
     int ntab = (p->width + p->height) * n1;

@@ -2,10 +2,11 @@
 
 The render path has no exchange step: samples are independent.  The only communication is
 (1) one byte broadcast of the flattened scene from rank 0 before the first frame and (2) one
-byte reduction of the RGBA8 frame to rank 0 after each frame.  Each rank renders the 32x32
+gather of each rank's OWN pixels to rank 0 after each frame.  Each rank renders the 32x32
 tiles whose id % world == rank (cyclic, so a mesh that covers part of the frame is spread
-evenly) into a zero-initialised full frame; tiles are disjoint, so a SUM reduction of the
-uint8 frames is exactly the composite.  With the `nccl` backend both calls are RCCL over xGMI.
+evenly).  A rank sends only the pixels it owns (1/world of the frame, packed), so rank 0
+receives (world-1)/world of a frame in total, each peer over its own xGMI link; with the
+`nccl` backend both calls are RCCL.
 """
 import copy
 
@@ -56,7 +57,38 @@ def broadcast_scene(data, src: int = 0, device="cpu", group=None):
     return data if rank == src else scenes.SceneData.from_arrays(out)
 
 
-def composite(frame: torch.Tensor, dst: int = 0, group=None):
-    """Sum-reduce the per-rank uint8 frames (disjoint tiles, zeros elsewhere) onto `dst`."""
-    dist.reduce(frame, dst, op=dist.ReduceOp.SUM, group=group)
-    return frame
+class TileComposer:
+    """Collects the per-rank tiles of a frame on rank 0.
+
+    Every rank owns `frame`, an [H, W, 4] uint8 tensor that its renderer writes its tiles into.
+    `compose()` packs the rank's own pixels (as one int32 per RGBA pixel), gathers the packs on
+    rank 0 and scatters them into rank 0's frame.  Index tensors are built once.
+    """
+
+    def __init__(self, width, height, rank, world, device, tile_size=TILE, group=None):
+        self.rank, self.world, self.group = rank, world, group
+        self.frame = torch.zeros((height, width, 4), dtype=torch.uint8, device=device)
+        self._flat = self.frame.view(torch.int32).view(-1)  # one element per pixel
+        idx = [np.flatnonzero(owned_pixel_mask(width, height, r, world, tile_size).ravel()) for r in range(world)]
+        self.counts = [len(i) for i in idx]
+        self.maxn = max(self.counts) if idx else 0
+        self._own_idx = torch.from_numpy(idx[rank]).to(device)
+        self._send = torch.zeros(self.maxn, dtype=torch.int32, device=device)
+        if rank == 0:
+            self._recv = torch.zeros((world, self.maxn), dtype=torch.int32, device=device)
+            # peers' pixels only (rank 0's own tiles are already in its frame)
+            self._peer_idx = [torch.from_numpy(idx[r]).to(device) for r in range(world)]
+
+    def compose(self):
+        """Returns rank 0's frame with every rank's tiles in place (None on other ranks)."""
+        if self.world == 1:
+            return self.frame
+        n = self.counts[self.rank]
+        torch.index_select(self._flat, 0, self._own_idx, out=self._send[:n])
+        if self.rank == 0:
+            dist.gather(self._send, list(self._recv.unbind(0)), dst=0, group=self.group)
+            for r in range(1, self.world):
+                self._flat.index_copy_(0, self._peer_idx[r], self._recv[r, : self.counts[r]])
+            return self.frame
+        dist.gather(self._send, None, dst=0, group=self.group)
+        return None

@@ -30,13 +30,22 @@ def _worker(rank, world, port, q):
         mask = sharding.owned_pixel_mask(100, 80, rank, world, 16)
         assert (rgba[~mask] == 0).all(), "a rank wrote outside its tiles"
         assert (rgba[mask][:, 3] == 255).all()
-        frame = sharding.composite(torch.from_numpy(rgba.copy()), 0)
+        comp = sharding.TileComposer(100, 80, rank, world, "cpu", tile_size=16)
+        comp.frame.copy_(torch.from_numpy(rgba))
+        frame = comp.compose()
+        # a second frame through the same composer (stale pixels must be overwritten)
+        cam2 = scenes.make_camera((0.4, 0.1, 4.0), (-0.1, 0.0, -1.0), 10.0)
+        rgba2, _, _ = oracle.render(data, cam2, p)
+        first = frame.numpy().copy() if rank == 0 else None
+        comp.frame.copy_(torch.from_numpy(rgba2))
+        frame2 = comp.compose()
         samples = torch.tensor([cnt["samples"]])
         dist.all_reduce(samples)
         if rank == 0:
             full, _, full_cnt = oracle.render(data, cam, params)
-            q.put(((frame.numpy() == full).all(), int(samples.item()) == full_cnt["samples"],
-                   len(data.triangles)))
+            full2, _, _ = oracle.render(data, cam2, params)
+            q.put((bool((first == full).all() and (frame2.numpy() == full2).all()),
+                   int(samples.item()) == full_cnt["samples"], len(data.triangles)))
     finally:
         dist.destroy_process_group()
 
