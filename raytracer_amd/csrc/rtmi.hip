@@ -537,37 +537,60 @@ k_resolve_top(SceneDev sc, const int* __restrict__ q_top, const int* __restrict_
 // mode 0: queue entries are sample ids awaiting the children of bounding object
 //         `obj_filter`; the result is written to hit_id[s] and hits are appended to q_shade.
 // mode 1: top-level runs; the result (triangle index or -1) goes to tri_hit[q].
+// Everything the search kernel needs besides the cone stream.  It lives in device memory and is
+// read where it is used (prologue, rare path, epilogue), so that the steady-state loop keeps its
+// scalar registers for the two triangle batches in flight.
+struct SearchArgs {
+  const int* queue;
+  const int* nq_ptr;
+  const int* npacked_ptr;
+  const float* edge;
+  const int* packed_tri;
+  const double* dirs;
+  double* tval;
+  int* hit_id;
+  int* tri_hit;
+  int* q_shade;
+  DevCounters* cnt;
+  const rtmi_triangle* tris;
+  const TriPlane* planes;
+  double cam[3];
+  int mode, obj_filter;
+};
+
 template <int R>
 __global__ void __launch_bounds__(256)
-k_search_primary(const FrameConst* __restrict__ fcp, SceneDev sc, const int* __restrict__ queue,
-                 const int* __restrict__ nq_ptr, int mode, int obj_filter, const f2* __restrict__ cone,
-                 const float* __restrict__ edge, const int* __restrict__ npacked_ptr,
-                 const int* __restrict__ packed_tri, const double* __restrict__ dirs, int* hit_id, int* tri_hit,
-                 int* q_shade, DevCounters* cnt) {
-  const int nq = *nq_ptr;
+k_search_primary(const SearchArgs* __restrict__ ap, const f2* __restrict__ cone) {
+  const int nq = *ap->nq_ptr;
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int base = wave * 64 * R;
   if ((int)(blockIdx.x * blockDim.x) * R >= nq) return;  // whole workgroup past the queue end
-  const int npacked = *npacked_ptr;
+  const int npacked = *ap->npacked_ptr;
   const int nbatch = base < nq ? (npacked + TRI_BATCH - 1) / TRI_BATCH : 0;
-  unsigned long long n_exact = 0;
+  unsigned int n_exact = 0;
 
   int sid[R], best[R], upto[R];
   float dx[R], dy[R], dz[R];
   const float qnan = __builtin_nanf("");
+  {
+    const int* queue = ap->queue;
+    const int* hit_id = ap->hit_id;
+    const double* dirs = ap->dirs;
+    const int mode = ap->mode, obj_filter = ap->obj_filter;
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    int q = base + r * 64 + lane;
-    bool valid = q < nq;
-    sid[r] = valid ? queue[q] : -1;
-    if (valid && mode == 0 && hit_id[sid[r]] != -2 - obj_filter) sid[r] = -1;
-    best[r] = -1;
-    upto[r] = 0;
-    dx[r] = dy[r] = dz[r] = qnan;
-    if (sid[r] >= 0) {
-      const double* dp = dirs + (size_t)sid[r] * 3;
-      dx[r] = (float)dp[0]; dy[r] = (float)dp[1]; dz[r] = (float)dp[2];
+    for (int r = 0; r < R; ++r) {
+      int q = base + r * 64 + lane;
+      bool valid = q < nq;
+      sid[r] = valid ? queue[q] : -1;
+      if (valid && mode == 0 && hit_id[sid[r]] != -2 - obj_filter) sid[r] = -1;
+      best[r] = -1;
+      upto[r] = 0;
+      dx[r] = dy[r] = dz[r] = qnan;
+      if (sid[r] >= 0) {
+        const double* dp = dirs + (size_t)sid[r] * 3;
+        dx[r] = (float)dp[0]; dy[r] = (float)dp[1]; dz[r] = (float)dp[2];
+      }
     }
   }
 
@@ -608,6 +631,9 @@ k_search_primary(const FrameConst* __restrict__ fcp, SceneDev sc, const int* __r
 
       if (__builtin_expect(__any(mx >= 1.0f) || flag != 0, 0)) {
         // ---- rare path: look closer at the eight triangles of this batch, in list order ----
+        const SearchArgs* a2 = ap;
+        asm volatile("" : "+s"(a2));  // read the argument block here, not ahead of the loop
+        const float* edge = a2->edge;
         for (int j = 0; j < TRI_BATCH; ++j) {
           const int g = b * TRI_BATCH + j;
           if (g >= npacked) break;
@@ -632,24 +658,35 @@ k_search_primary(const FrameConst* __restrict__ fcp, SceneDev sc, const int* __r
             if (!(e <= 1.0f)) nom &= ~(1u << r);
           }
           if (!__any(nom != 0)) continue;
-          const int ti = packed_tri[g];
-          const rtmi_triangle& tr = sc.tris[ti];
-          const d3 v0 = rtx::ld3(tr.v[0]), v1 = rtx::ld3(tr.v[1]), v2 = rtx::ld3(tr.v[2]);
-          const TriPlane pl = sc.planes[ti];
-          const d3 cam = rtx::ld3(fcp->cam);
-#pragma unroll
+          // FP64 decision, one ray slot at a time.  The loop over r is deliberately NOT unrolled:
+          // one copy of the double-precision code keeps the kernel's register count (and with it
+          // the occupancy of the steady-state loop) low; r is wave-uniform, so the selects below
+          // are scalar branches.
+          const int ti = a2->packed_tri[g];
+#pragma nounroll
           for (int r = 0; r < R; ++r) {
-            if (!__any((nom >> r) & 1u)) continue;
-            if ((nom >> r) & 1u) {
-              const double* dp = dirs + (size_t)sid[r] * 3;
-              d3 d = rtx::mk(dp[0], dp[1], dp[2]);
-              double t;
+            const bool mine = (nom >> r) & 1u;
+            if (!__any(mine)) continue;
+            int s = sid[0];
+#pragma unroll
+            for (int rr = 1; rr < R; ++rr) if (rr == r) s = sid[rr];
+            bool hit = false;
+            double t = 0.0;
+            if (mine) {
+              const rtmi_triangle& tr = a2->tris[ti];
+              const double* dp = a2->dirs + (size_t)s * 3;
               d3 P;
               n_exact += 1;
-              if (rtx::tri_hit(v0, v1, v2, pl, cam, d, &t, &P)) {
-                best[r] = ti;
-                upto[r] = g + 1;  // list positions this ray consumed
-                dx[r] = dy[r] = dz[r] = qnan;
+              hit = rtx::tri_hit(rtx::ld3(tr.v[0]), rtx::ld3(tr.v[1]), rtx::ld3(tr.v[2]), a2->planes[ti],
+                                 rtx::ld3(a2->cam), rtx::mk(dp[0], dp[1], dp[2]), &t, &P);
+              if (hit) a2->tval[s] = t;  // the hit point is origin + t*direction; shading rebuilds it
+            }
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) {
+              if (rr == r && hit) {
+                best[rr] = ti;
+                upto[rr] = g + 1;  // list positions this ray consumed
+                dx[rr] = dy[rr] = dz[rr] = qnan;
               }
             }
           }
@@ -673,11 +710,14 @@ k_search_primary(const FrameConst* __restrict__ fcp, SceneDev sc, const int* __r
   for (int r = 0; r < R; ++r) {
     if (sid[r] >= 0) tests += best[r] >= 0 ? (unsigned long long)upto[r] : walked;
   }
+  DevCounters* cnt = ap->cnt;
   wave_count(cnt, C_TESTS_PRIMARY, tests);
-  wave_count(cnt, C_EXACT, n_exact);
+  wave_count(cnt, C_EXACT, (unsigned long long)n_exact);
 
-  if (mode == 0) {
+  if (ap->mode == 0) {
     // hits go to the shade queue: one returning atomic per workgroup for all R rays
+    int* hit_id = ap->hit_id;
+    int* q_shade = ap->q_shade;
     __shared__ int wtot[4];
     __shared__ int gbase;
     const int w = threadIdx.x >> 6;
@@ -704,6 +744,7 @@ k_search_primary(const FrameConst* __restrict__ fcp, SceneDev sc, const int* __r
       pos += __popcll(masks[r]);
     }
   } else {
+    int* tri_hit = ap->tri_hit;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       int q = base + r * 64 + lane;
@@ -754,7 +795,9 @@ __device__ RGBd calculate_lighting(const SceneDev& sc, const FrameConst& fc, con
   }
   if (!is.has_normal) return I;  // RTF:199-202
   d3 normal = is.n;
-  d3 surface_to_camera = rtx::normalize(rtx::sub(camera, surface_point));  // RTF:204
+  // RTF:204; only the reflection direction and the specular term read it
+  d3 surface_to_camera = rtx::mk(0.0, 0.0, 0.0);
+  if (REFLECT || has_material) surface_to_camera = rtx::normalize(rtx::sub(camera, surface_point));
 
   if constexpr (REFLECT) {  // RTF:207-224
     d3 incident = rtx::neg(surface_to_camera);
@@ -801,7 +844,8 @@ __device__ RGBd calculate_lighting(const SceneDev& sc, const FrameConst& fc, con
 }
 
 __global__ void __launch_bounds__(256)
-k_shade(FrameConst fc, SceneDev sc, const double* __restrict__ dirs, const int* __restrict__ q_shade,
+k_shade(FrameConst fc, SceneDev sc, const double* __restrict__ dirs, const double* __restrict__ tval,
+        const int* __restrict__ q_shade,
         const int* __restrict__ nq_ptr, const int* __restrict__ hit_id, double* rgb, DevCounters* cnt) {
   int q = blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long n_refl = 0, n_shadow = 0, n_hit = 0;
@@ -815,7 +859,11 @@ k_shade(FrameConst fc, SceneDev sc, const double* __restrict__ dirs, const int* 
     if (id >= 0) {
       const rtmi_triangle& tr = sc.tris[id];
       const TriPlane pl = sc.planes[id];
-      ok = rtx::tri_hit(rtx::ld3(tr.v[0]), rtx::ld3(tr.v[1]), rtx::ld3(tr.v[2]), pl, cam, d, &h.t, &h.P);
+      // the search already decided this hit with Triangle.intersections; rebuild its point
+      // exactly as Renderables.swift:153 does: origin + intersectionParameter * direction
+      ok = true;
+      h.t = tval[s];
+      h.P = rtx::add(cam, rtx::smul(h.t, d));
       h.n = rtx::mk(pl.nx, pl.ny, pl.nz);
       h.has_normal = 1;
       h.material = tr.material;
@@ -920,8 +968,11 @@ struct rtmi_scene {
   int* d_q_top = nullptr;
   double* d_rgb = nullptr;
   double* d_dirs = nullptr;
+  double* d_tval = nullptr;
   FrameConst* d_fc = nullptr;
   FrameConst h_fc{};
+  std::vector<SearchArgs> h_sargs;   // one argument block per triangle group
+  SearchArgs* d_sargs = nullptr;
   double* d_tabs = nullptr;  // utab then vtab
   size_t cap_tabs = 0;
   int2* d_blocks = nullptr;
@@ -1045,7 +1096,7 @@ extern "C" void rtmi_scene_destroy(rtmi_scene* sc) {
   (void)hipFree(sc->d_tris); (void)hipFree(sc->d_planes); (void)hipFree(sc->d_tri_owner);
   (void)hipFree(sc->d_hit_id); (void)hipFree(sc->d_tri_hit); (void)hipFree(sc->d_q_child);
   (void)hipFree(sc->d_q_shade); (void)hipFree(sc->d_q_top); (void)hipFree(sc->d_rgb);
-  (void)hipFree(sc->d_dirs); (void)hipFree(sc->d_fc); (void)hipFree(sc->d_tabs);
+  (void)hipFree(sc->d_dirs); (void)hipFree(sc->d_tval); (void)hipFree(sc->d_fc); (void)hipFree(sc->d_tabs); (void)hipFree(sc->d_sargs);
   (void)hipFree(sc->d_blocks); (void)hipFree(sc->d_cnt);
   if (sc->ev_a) (void)hipEventDestroy(sc->ev_a);
   if (sc->ev_b) (void)hipEventDestroy(sc->ev_b);
@@ -1141,6 +1192,8 @@ static int32_t scene_create_impl(const rtmi_scene_desc* desc, int32_t device, rt
   }
   HIP_TRY(hipMalloc(&sc->d_cnt, sizeof(DevCounters)));
   HIP_TRY(hipMalloc(&sc->d_fc, sizeof(FrameConst)));
+  sc->h_sargs.resize(sc->groups.size());
+  HIP_TRY(hipMalloc(&sc->d_sargs, sizeof(SearchArgs) * sc->groups.size()));
   HIP_TRY(hipStreamSynchronize(sc->stream));
 
   sc->dev.objects = sc->d_objects;
@@ -1175,9 +1228,9 @@ static int32_t ensure_buffers(rtmi_scene* sc, size_t samples, size_t blocks) {
   if (samples > sc->cap_samples) {
     (void)hipFree(sc->d_hit_id); (void)hipFree(sc->d_tri_hit); (void)hipFree(sc->d_q_child);
     (void)hipFree(sc->d_q_shade); (void)hipFree(sc->d_q_top); (void)hipFree(sc->d_rgb);
-    (void)hipFree(sc->d_dirs);
+    (void)hipFree(sc->d_dirs); (void)hipFree(sc->d_tval);
     sc->d_hit_id = sc->d_tri_hit = sc->d_q_child = sc->d_q_shade = sc->d_q_top = nullptr;
-    sc->d_rgb = sc->d_dirs = nullptr;
+    sc->d_rgb = sc->d_dirs = sc->d_tval = nullptr;
     sc->cap_samples = 0;
     HIP_TRY(hipMalloc(&sc->d_hit_id, sizeof(int) * samples));
     HIP_TRY(hipMalloc(&sc->d_tri_hit, sizeof(int) * samples));
@@ -1186,6 +1239,7 @@ static int32_t ensure_buffers(rtmi_scene* sc, size_t samples, size_t blocks) {
     HIP_TRY(hipMalloc(&sc->d_q_top, sizeof(int) * samples));
     HIP_TRY(hipMalloc(&sc->d_rgb, sizeof(double) * 3 * samples));
     HIP_TRY(hipMalloc(&sc->d_dirs, sizeof(double) * 3 * samples));
+    HIP_TRY(hipMalloc(&sc->d_tval, sizeof(double) * samples));
     sc->cap_samples = samples;
   }
   if (blocks > sc->cap_blocks) {
@@ -1344,6 +1398,29 @@ static int32_t render_impl(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_pa
   for (auto& g : sc->groups)
     if ((rc = pack_group(sc, g, camera))) return rc;
 
+  // argument blocks of the search launches (one per triangle group), uploaded once per frame
+  for (size_t gi = 0; gi < sc->groups.size(); ++gi) {
+    const TriGroup& g = sc->groups[gi];
+    SearchArgs& a = sc->h_sargs[gi];
+    a.queue = gi == 0 ? sc->d_q_top : sc->d_q_child;
+    a.nq_ptr = gi == 0 ? &sc->d_cnt->q_top : &sc->d_cnt->q_child;
+    a.npacked_ptr = g.d_npacked;
+    a.edge = g.d_edge;
+    a.packed_tri = g.d_packed_tri;
+    a.dirs = sc->d_dirs;
+    a.tval = sc->d_tval;
+    a.hit_id = sc->d_hit_id;
+    a.tri_hit = sc->d_tri_hit;
+    a.q_shade = sc->d_q_shade;
+    a.cnt = sc->d_cnt;
+    a.tris = sc->d_tris;
+    a.planes = sc->d_planes;
+    a.cam[0] = fc.cam[0]; a.cam[1] = fc.cam[1]; a.cam[2] = fc.cam[2];
+    a.mode = gi == 0 ? 1 : 0;
+    a.obj_filter = g.object;
+  }
+  HIP_TRY(hipMemcpyAsync(sc->d_sargs, sc->h_sargs.data(), sizeof(SearchArgs) * sc->groups.size(), hipMemcpyHostToDevice, st));
+
   float ms_search = 0.f, ms_primary = 0.f;
   long long launches = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;
@@ -1364,9 +1441,7 @@ static int32_t render_impl(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_pa
       hipEvent_t e0, e1;
       HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
       HIP_TRY(hipEventRecord(e0, st));
-      hipLaunchKernelGGL(search_kernel, dim3(search_grid), dim3(256), 0, st, sc->d_fc, sc->dev, sc->d_q_top,
-                         &sc->d_cnt->q_top, 1, -1, (const f2*)g.d_cone, g.d_edge, g.d_npacked, g.d_packed_tri,
-                         sc->d_dirs, sc->d_hit_id, sc->d_tri_hit, sc->d_q_shade, sc->d_cnt);
+      hipLaunchKernelGGL(search_kernel, dim3(search_grid), dim3(256), 0, st, sc->d_sargs + 0, (const f2*)g.d_cone);
       HIP_TRY(hipEventRecord(e1, st));
       timed.emplace_back(e0, e1);
       ++launches;
@@ -1378,14 +1453,12 @@ static int32_t render_impl(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_pa
       hipEvent_t e0, e1;
       HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
       HIP_TRY(hipEventRecord(e0, st));
-      hipLaunchKernelGGL(search_kernel, dim3(search_grid), dim3(256), 0, st, sc->d_fc, sc->dev, sc->d_q_child,
-                         &sc->d_cnt->q_child, 0, g.object, (const f2*)g.d_cone, g.d_edge, g.d_npacked, g.d_packed_tri,
-                         sc->d_dirs, sc->d_hit_id, sc->d_tri_hit, sc->d_q_shade, sc->d_cnt);
+      hipLaunchKernelGGL(search_kernel, dim3(search_grid), dim3(256), 0, st, sc->d_sargs + gi, (const f2*)g.d_cone);
       HIP_TRY(hipEventRecord(e1, st));
       timed.emplace_back(e0, e1);
       ++launches;
     }
-    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(256), 0, st, fc, sc->dev, sc->d_dirs, sc->d_q_shade, &sc->d_cnt->q_shade,
+    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(256), 0, st, fc, sc->dev, sc->d_dirs, sc->d_tval, sc->d_q_shade, &sc->d_cnt->q_shade,
                        sc->d_hit_id, sc->d_rgb, sc->d_cnt);
     int npix = (int)(nb * BLK_PIX);
     hipLaunchKernelGGL(k_resolve, dim3((npix + 255) / 256), dim3(256), 0, st, fc, d_blk, npix, sc->d_hit_id, sc->d_rgb,
