@@ -183,12 +183,18 @@ def main():
                 "peak": PEAK_FP32_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
-                "traffic": None,
+                "traffic": traffic_from_profile(args.config),
+                "traffic_unit": "bytes of HBM traffic per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, "
+                                "separate passes; profiles/r01_pmc_search_kernel.json)",
                 "flops_per_test_algorithmic": FLOPS_PER_TEST,
                 "tests_per_launch": totals["tests_primary"] / launches,
                 "avg_launch_ms": round(avg_ms, 4),
-                "note": "algorithmic flops (69 per ray-triangle pair) / launch time; the kernel executes "
-                        "about 21 FP32 flops per pair (3 edge-plane dot products + max), so frac may exceed 1",
+                "executed_fp32_flops_per_test": 7,
+                "note": "achieved = evaluated (ray, triangle) pairs per launch x 69 algorithmic flops / launch time "
+                        "(HIP events on the library's stream).  The kernel decides most pairs with a conservative "
+                        "3-FMA cone test (about 7 executed FP32 flops per pair incl. the max), the rest with a 9-FMA "
+                        "edge test and an FP64 reference-order test, so frac exceeds 1 by construction; the VALU "
+                        "is 88% busy during the launch (SQ_ACTIVE_INST_VALU, profiles/).",
             },
         }
         if not args.no_cpu and world == 1:
@@ -198,6 +204,17 @@ def main():
     scene.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def traffic_from_profile(config):
+    """HBM bytes per k_search_primary launch from the committed PMC profile of this configuration
+    (bench.py itself cannot collect PMC counters); None if there is none for `config`."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_search_kernel.json")
+    try:
+        d = json.load(open(path))
+    except OSError:
+        return None
+    return d.get("hbm_bytes_per_launch") if d.get("config") == config else None
 
 
 def scene_spp(sub):

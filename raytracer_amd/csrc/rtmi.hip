@@ -329,32 +329,27 @@ __global__ void k_pack_write(const rtmi_triangle* __restrict__ tris, const int* 
 // top-level tests against spheres, bounding spheres and lights (FP64, list order)
 // ---------------------------------------------------------------------------------------
 struct Hit {
-  d3 P, n;
+  d3 P, n;        // n is the unit normal, or (n_unit == 0) the un-normalised P - centre of a sphere
   double t;
   int has_normal;
+  int n_unit;
   int material;
   int id;  // triangle index, or -2 - object index
 };
 
-// intersections[0] over the sphere-like members of the top-level list, skipping triangle
-// runs (they are searched separately).  Returns the object index or -1.
-__device__ inline int first_sphere_like(const SceneDev& sc, d3 o, d3 d, Hit* h) {
+// Index of the first sphere-like member of the top-level list (sphere, bounding sphere or
+// light) that the ray intersects at all, skipping triangle runs (they are searched
+// separately); -1 if none.  Only the index is needed here: a bounding sphere's own hit point is
+// never used (RayTracingFunctions.swift:85-93) and shading recomputes a sphere's.
+__device__ inline int first_sphere_like(const SceneDev& sc, d3 o, d3 d) {
   for (int k = 0; k < sc.n_objects; ++k) {
     const rtmi_object& ob = sc.objects[k];
     if (ob.kind == RTMI_SPHERE || ob.kind == RTMI_BOUNDING_SPHERE) {
-      double t;
-      d3 P, n;
-      if (rtx::sphere_first(rtx::ld3(ob.center), ob.radius, o, d, &t, &P, &n)) {
-        h->P = P; h->n = n; h->t = t; h->has_normal = 1; h->material = ob.material; h->id = -2 - k;
-        return k;
-      }
+      if (rtx::sphere_any(rtx::ld3(ob.center), ob.radius, o, d)) return k;
     } else if (ob.kind == RTMI_LIGHT) {
       double t;
       d3 P;
-      if (rtx::light_hit(rtx::ld3(sc.lights[ob.first].loc), o, d, &t, &P)) {
-        h->P = P; h->t = t; h->has_normal = 0; h->material = -1; h->id = -2 - k;
-        return k;
-      }
+      if (rtx::light_hit(rtx::ld3(sc.lights[ob.first].loc), o, d, &t, &P)) return k;
     }
   }
   return -1;
@@ -383,10 +378,13 @@ __device__ inline bool trace_top_secondary(const SceneDev& sc, d3 o, d3 d, bool 
       double t;
       d3 P, n;
       if (want_first && !found) {
-        if (rtx::sphere_first(rtx::ld3(ob.center), ob.radius, o, d, &t, &P, &n)) {
+        if (rtx::sphere_first_raw(rtx::ld3(ob.center), ob.radius, o, d, &t, &P, &n)) {
           found = true;
           if (ob.kind == RTMI_SPHERE) anb = true;
-          h->P = P; h->n = n; h->t = t; h->has_normal = 1; h->material = ob.material; h->id = -2 - k;
+          // without a material only the SIGN of normal.light is ever read (calculate_lighting)
+          h->n_unit = ob.material >= 0;
+          h->P = P; h->n = h->n_unit ? rtx::normalize(n) : n; h->t = t; h->has_normal = 1;
+          h->material = ob.material; h->id = -2 - k;
         }
       } else if (ob.kind == RTMI_SPHERE) {
         if (rtx::sphere_any(rtx::ld3(ob.center), ob.radius, o, d)) anb = true;
@@ -400,7 +398,7 @@ __device__ inline bool trace_top_secondary(const SceneDev& sc, d3 o, d3 d, bool 
         if (!found) {
           found = true;
           const TriPlane pl = sc.planes[i];
-          h->P = P; h->n = rtx::mk(pl.nx, pl.ny, pl.nz); h->t = t; h->has_normal = 1;
+          h->P = P; h->n = rtx::mk(pl.nx, pl.ny, pl.nz); h->t = t; h->has_normal = 1; h->n_unit = 1;
           h->material = sc.tris[i].material; h->id = (int)i;
         }
       }
@@ -411,7 +409,7 @@ __device__ inline bool trace_top_secondary(const SceneDev& sc, d3 o, d3 d, bool 
         anb = true;
         if (!found) {
           found = true;
-          h->P = P; h->t = t; h->has_normal = 0; h->material = -1; h->id = -2 - k;
+          h->P = P; h->t = t; h->has_normal = 0; h->n_unit = 1; h->material = -1; h->id = -2 - k;
         }
       }
     }
@@ -448,8 +446,7 @@ k_gen(FrameConst fc, SceneDev sc, const int2* __restrict__ blocks, int nsamples,
     bool to_child = false, to_shade = false;
     if (live) {
       d3 d = sample_dir(fc, x, y, k);
-      Hit h;
-      int obj = first_sphere_like(sc, rtx::ld3(fc.cam), d, &h);
+      int obj = first_sphere_like(sc, rtx::ld3(fc.cam), d);
       if (obj >= 0) {
         id = -2 - obj;
         if (sc.objects[obj].kind == RTMI_BOUNDING_SPHERE) to_child = true; else to_shade = true;
@@ -779,6 +776,27 @@ __device__ inline double spec_pow(double base, double e) {
   return pow(base, e);
 }
 
+// Number of lights with normalLightVectorDp > 0 (RayTracingFunctions.swift:227-232) at a hit whose
+// object has no material.  There the light loop adds nothing to the colour (:245), but every
+// such light still costs the reference one shadow ray (:236), which the counters report.  The
+// sign of dp(normalize(L), normalize(N)) equals the sign of dp(L, N) whenever |dp(L, N)| exceeds
+// 2^-40 |L|_1 |N|_1 (the rounding of the normalised form is below 2^-48); only inside that band
+// are the two normalisations evaluated.
+__device__ inline int count_facing_lights(const SceneDev& sc, d3 P, d3 n, bool n_unit) {
+  int c = 0;
+  const double n1 = fabs(n.x) + fabs(n.y) + fabs(n.z);
+  for (int li = 0; li < sc.n_lights; ++li) {
+    d3 L = rtx::sub(rtx::ld3(sc.lights[li].loc), P);
+    double sdp = rtx::dp(L, n);
+    double band = 9.094947017729282e-13 * ((fabs(L.x) + fabs(L.y) + fabs(L.z)) * n1);
+    if (sdp > band) { ++c; continue; }
+    if (sdp < -band) continue;
+    d3 nn = n_unit ? n : rtx::normalize(n);
+    if (rtx::dp(rtx::normalize(L), nn) > 0) ++c;
+  }
+  return c;
+}
+
 template <bool REFLECT>
 __device__ RGBd calculate_lighting(const SceneDev& sc, const FrameConst& fc, const Hit& is, d3 camera,
                                    unsigned long long* n_refl, unsigned long long* n_shadow) {
@@ -794,6 +812,11 @@ __device__ RGBd calculate_lighting(const SceneDev& sc, const FrameConst& fc, con
     I.b = mat.Ka[2] * fc.ambient[2];
   }
   if (!is.has_normal) return I;  // RTF:199-202
+  if (!REFLECT && !has_material) {
+    // nothing below can change I (= 0); only the shadow rays are counted
+    *n_shadow += count_facing_lights(sc, surface_point, is.n, is.n_unit);
+    return I;
+  }
   d3 normal = is.n;
   // RTF:204; only the reflection direction and the specular term read it
   d3 surface_to_camera = rtx::mk(0.0, 0.0, 0.0);
@@ -814,6 +837,11 @@ __device__ RGBd calculate_lighting(const SceneDev& sc, const FrameConst& fc, con
     I.b = I.b + contribution.b;
   }
 
+  if (!has_material) {  // the light loop adds nothing (RTF:245); count its shadow rays
+    *n_shadow += count_facing_lights(sc, surface_point, normal, true);
+    I.r = rtx::clamp01(I.r); I.g = rtx::clamp01(I.g); I.b = rtx::clamp01(I.b);  // RTF:269
+    return I;
+  }
   for (int li = 0; li < sc.n_lights; ++li) {  // RTF:226-268
     const rtmi_light& light = sc.lights[li];
     d3 point_to_light = rtx::normalize(rtx::sub(rtx::ld3(light.loc), surface_point));
@@ -866,6 +894,7 @@ k_shade(FrameConst fc, SceneDev sc, const double* __restrict__ dirs, const doubl
       h.P = rtx::add(cam, rtx::smul(h.t, d));
       h.n = rtx::mk(pl.nx, pl.ny, pl.nz);
       h.has_normal = 1;
+      h.n_unit = 1;
       h.material = tr.material;
       h.id = id;
     } else {
@@ -873,10 +902,12 @@ k_shade(FrameConst fc, SceneDev sc, const double* __restrict__ dirs, const doubl
       if (ob.kind == RTMI_LIGHT) {
         ok = rtx::light_hit(rtx::ld3(sc.lights[ob.first].loc), cam, d, &h.t, &h.P);
         h.has_normal = 0;
+        h.n_unit = 1;
         h.material = -1;
       } else {
         ok = rtx::sphere_first(rtx::ld3(ob.center), ob.radius, cam, d, &h.t, &h.P, &h.n);
         h.has_normal = 1;
+        h.n_unit = 1;
         h.material = ob.material;
       }
       h.id = id;

@@ -102,9 +102,10 @@ RT_HD bool tri_hit(d3 v0, d3 v1, d3 v2, const TriPlane& pl, d3 origin, d3 direct
 }
 
 // Sphere.intersections (REN:248-282) reduced to its first element: the smallest root that
-// passes the >= 1e-7 filter, with its point and outward normal.
-RT_HD bool sphere_first(d3 location, double radius, d3 origin, d3 direction, double* t_out,
-                        d3* P_out, d3* n_out) {
+// passes the >= 1e-7 filter, with its point and the un-normalised outward vector p - location
+// (REN:276 normalises it; callers that never read the normal skip that).
+RT_HD bool sphere_first_raw(d3 location, double radius, d3 origin, d3 direction, double* t_out,
+                            d3* P_out, d3* raw_n_out) {
   double radius_squared = radius * radius;  // pow(radius, 2), REN:210/:243
   d3 center_to_eye = sub(origin, location);
   double a = -dp(direction, center_to_eye);
@@ -127,7 +128,15 @@ RT_HD bool sphere_first(d3 location, double radius, d3 origin, d3 direction, dou
   d3 p = add(origin, smul(t, direction));
   *t_out = t;
   *P_out = p;
-  *n_out = normalize(sub(p, location));
+  *raw_n_out = sub(p, location);
+  return true;
+}
+
+RT_HD bool sphere_first(d3 location, double radius, d3 origin, d3 direction, double* t_out,
+                        d3* P_out, d3* n_out) {
+  d3 raw;
+  if (!sphere_first_raw(location, radius, origin, direction, t_out, P_out, &raw)) return false;
+  *n_out = normalize(raw);
   return true;
 }
 
