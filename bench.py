@@ -92,7 +92,7 @@ def main():
             return scenes.make_camera(**scenes.orbit_camera(step % 64))
         return scenes.make_camera(**scenes.MESH_CAMERA)
 
-    totals = {"rays": 0, "tests": 0, "tests_primary": 0, "ms_primary": 0.0, "launches": 0, "ms_total": 0.0,
+    totals = {"rays": 0, "refl": 0, "shadow": 0, "elided": 0, "tests": 0, "tests_primary": 0, "ms_primary": 0.0, "launches": 0, "ms_total": 0.0,
               "exact": 0, "samples": 0}
 
     def step(i, record):
@@ -103,6 +103,9 @@ def main():
         if record:
             totals["rays"] += cnt["samples"] + cnt["rays_reflection"] + cnt["rays_shadow"]
             totals["samples"] += cnt["samples"]
+            totals["refl"] += cnt["rays_reflection"]
+            totals["shadow"] += cnt["rays_shadow"]
+            totals["elided"] += cnt["shadow_rays_elided"]
             totals["tests"] += cnt["tri_tests"]
             totals["tests_primary"] += cnt["tri_tests_primary_kernel"]
             totals["ms_primary"] += cnt["ms_primary_kernel"]
@@ -173,6 +176,12 @@ def main():
             },
             "verified_against_single_gpu_frame": verified,
             "rays_per_step": int(total_rays / args.steps),
+            "rays_per_step_rank0": {"primary": totals["samples"] // args.steps, "reflection": totals["refl"] // args.steps,
+                                    "shadow": totals["shadow"] // args.steps,
+                                    "shadow_elided": totals["elided"] // args.steps,
+                                    "note": "ray counts follow the reference (the oracle's counters); 'shadow_elided' of the "
+                                            "shadow rays start at hits on material-less objects and are not traced because "
+                                            "their outcome cannot change the pixel"},
             "tests_per_s": tests_per_s,
             "tests_per_s_frac_of_fp32_roofline": tests_per_s * FLOPS_PER_TEST / (PEAK_FP32_TFLOPS * 1e12 * world),
             "device_ms_per_step_rank0": round(totals["ms_total"] / args.steps, 4),

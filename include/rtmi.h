@@ -131,7 +131,11 @@ typedef struct {
   int64_t sphere_tests;     /* (ray, sphere|light) pairs evaluated                       */
   int64_t tri_exact_tests;  /* pairs that went through the FP64 reference-order test     */
   int64_t primary_hits;     /* samples that were shaded                                  */
-  int64_t reserved_[3];
+  int64_t shadow_rays_elided; /* of rays_shadow: rays from hits on material-less objects,
+                                 counted like the reference counts them but not traced, since
+                                 nothing they could hit can change the pixel
+                                 (RayTracingFunctions.swift:245)                          */
+  int64_t reserved_[2];
   double ms_total;          /* device time of the whole call (HIP events)                */
   double ms_tri_search;     /* device time of the triangle search launches only          */
   int64_t tri_search_launches;

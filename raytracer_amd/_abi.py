@@ -65,7 +65,7 @@ class Counters(C.Structure):
     _fields_ = [("samples", C.c_int64), ("rays_reflection", C.c_int64), ("rays_shadow", C.c_int64),
                 ("tri_tests", C.c_int64), ("sphere_tests", C.c_int64),
                 ("tri_exact_tests", C.c_int64), ("primary_hits", C.c_int64),
-                ("reserved_", C.c_int64 * 3), ("ms_total", C.c_double), ("ms_tri_search", C.c_double),
+                ("shadow_rays_elided", C.c_int64), ("reserved_", C.c_int64 * 2), ("ms_total", C.c_double), ("ms_tri_search", C.c_double),
                 ("tri_search_launches", C.c_int64), ("tri_tests_primary_kernel", C.c_int64),
                 ("ms_primary_kernel", C.c_double)]
 

@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <array>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -59,6 +60,8 @@ constexpr int TRI_BATCH = 8;        // triangles per scalar-load batch of the co
 constexpr int CONE_DWORDS = 32;     // per batch: 4 pairs x 3 components x (tri a, tri b) + flag + pad
 constexpr int CONE_FLAG = 24;       // dword index of the batch's "always look closer" flag
 constexpr int EDGE_FLOATS = 9;      // per triangle: 3 scaled edge-plane vectors
+constexpr int GSPH_BATCH = 4;       // triangles per scalar-load batch of the general-origin sphere test
+constexpr int GST2_FLOATS = 32;     // per triangle: plane (4) + bounds (5) + 3 x (w, e) (18), padded
 
 struct FrameConst {
   double ul[3], u[3], v[3], cam[3];
@@ -74,7 +77,7 @@ struct FrameConst {
 
 // Work counters are striped over NSLOT cache lines (one 64-byte line per slot) so that the
 // per-wave atomic adds of a launch do not serialise on one address; the host sums the slots.
-enum { C_REFL = 0, C_SHADOW, C_EXACT, C_HITS, C_TESTS_PRIMARY, C_NCOUNTERS = 8 };
+enum { C_REFL = 0, C_SHADOW, C_EXACT, C_HITS, C_TESTS_PRIMARY, C_TESTS_SECONDARY, C_SHADOW_ELIDED, C_NCOUNTERS = 8 };
 constexpr int NSLOT = 64;
 
 struct DevCounters {
@@ -91,6 +94,12 @@ struct SceneDev {
   const TriPlane* planes;
   int n_objects, n_lights, n_sphere_like;
   long long n_top_tris;
+  // general-origin filter of the top-level triangle runs (secondary rays), built once per scene
+  const float* gsph;     // per 4 triangles: 16 floats, see k_pack_general
+  const float* gst2;     // per triangle: GST2_FLOATS floats
+  const int* top_group;  // top-level ordinal -> triangle index
+  const int* run_start;  // object index -> first top-level ordinal of its run
+  double c0[3];          // centre the FP32 filter coordinates are relative to
 };
 
 // Pixel `pix` (0..63, row-major in the 8x8 block) of block `b`; false if it is not rendered.
@@ -325,6 +334,73 @@ __global__ void k_pack_write(const rtmi_triangle* __restrict__ tris, const int* 
   packed_tri[pos] = ti;
 }
 
+// General-origin filter data for the top-level triangle runs (rays that start on surfaces:
+// reflection and shadow rays, RayTracingFunctions.swift:212,236).  All FP32 values are relative
+// to the centre c0; r_o1 bounds |o - c0|_1 over every possible ray origin (scene bounds).
+//
+// (1) Sphere test, packed two triangles per instruction.  With c the centroid, rho the largest
+//     vertex distance from it and m = c - o, a hit needs the ray's LINE within rho of c:
+//     (d.m)^2 + rho^2 - |m|^2 >= 0.  Expanded so that every term is a dot product with a
+//     per-triangle scalar operand: A = d.c - d.o, T = A*A + (2 c.o - |o|^2), nominate iff
+//     T + nK >= 0 with nK = rho^2 + delta - |c|^2.  delta = 64*2^-24*(|c|_1 + r_o1)^2 exceeds the FP32
+//     evaluation error of T (about 40*2^-24*(|c|_1+|o|_1)^2).
+// (2) Plane and edge tests (Pluecker form), per nominated triangle:
+//       n.d <= Ea                        (Renderables.swift:146, front face)
+//       n.o - cpl >= -Eb                 (t > 0, :150-152, given n.d < 0)
+//       d.w_i + (o x d).e_i <= E_i       (:158-163; w_i = v_i x v_j, e_i = v_j - v_i, because
+//                                         d.((v_i-o)x(v_j-o)) = d.(v_i x v_j) + (o x d).(v_j - v_i))
+//     each bound 16*2^-24 times the sum of the magnitudes that enter the FP32 evaluation.
+// Pairs that pass everything are decided by rtx::tri_hit in FP64.
+__global__ void k_pack_general(const rtmi_triangle* __restrict__ tris, const int* __restrict__ group, int n, d3 c0,
+                               double r_o1, float* gsph, float* gst2) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const rtmi_triangle& t = tris[group[i]];
+  d3 v[3];
+  for (int q = 0; q < 3; ++q) v[q] = rtx::sub(rtx::ld3(t.v[q]), c0);
+  const double eps32 = 5.9604644775390625e-08;  // 2^-24
+  // (1)
+  d3 c = rtx::mk((v[0].x + v[1].x + v[2].x) / 3.0, (v[0].y + v[1].y + v[2].y) / 3.0, (v[0].z + v[1].z + v[2].z) / 3.0);
+  double rho2 = 0;
+  for (int q = 0; q < 3; ++q) rho2 = fmax(rho2, rtx::len_squared(rtx::sub(v[q], c)));
+  double s1 = fabs(c.x) + fabs(c.y) + fabs(c.z) + r_o1;
+  double nK = rho2 * (1.0 + 1e-6) + 64.0 * eps32 * s1 * s1 - rtx::len_squared(c);
+  float fx = (float)c.x, fy = (float)c.y, fz = (float)c.z, fk = (float)nK;
+  if (!isfinite(fx) || !isfinite(fy) || !isfinite(fz) || !isfinite(fk)) { fx = fy = fz = 0.f; fk = 3.0e38f; }  // always nominate
+  {
+    int b = i / GSPH_BATCH, j = i % GSPH_BATCH;
+    float* dst = gsph + (size_t)b * 16 + (j >> 1) * 8 + (j & 1);
+    dst[0] = fx; dst[2] = fy; dst[4] = fz; dst[6] = fk;
+  }
+  // (2)
+  float* o = gst2 + (size_t)i * GST2_FLOATS;
+  d3 e01 = rtx::sub(v[1], v[0]), e02 = rtx::sub(v[2], v[0]);
+  d3 nn = rtx::normalize(rtx::cross(e01, e02));
+  double cpl = rtx::dp(nn, v[0]);
+  double n1 = fabs(nn.x) + fabs(nn.y) + fabs(nn.z);
+  o[0] = (float)nn.x; o[1] = (float)nn.y; o[2] = (float)nn.z; o[3] = (float)cpl;
+  o[4] = (float)(16.0 * eps32 * n1);                          // Ea
+  o[5] = (float)(16.0 * eps32 * (n1 * r_o1 + fabs(cpl)));     // Eb
+  for (int e = 0; e < 3; ++e) {
+    d3 a = v[e], b2 = v[(e + 1) % 3];
+    d3 w = rtx::cross(a, b2), ed = rtx::sub(b2, a);
+    double E = 16.0 * eps32 * ((fabs(w.x) + fabs(w.y) + fabs(w.z)) + 2.0 * r_o1 * (fabs(ed.x) + fabs(ed.y) + fabs(ed.z))) +
+               9.094947017729282e-13 * (s1 * s1);
+    o[6 + e] = (float)E;
+    float* q = o + 9 + e * 6;
+    q[0] = (float)w.x; q[1] = (float)w.y; q[2] = (float)w.z;
+    q[3] = (float)ed.x; q[4] = (float)ed.y; q[5] = (float)ed.z;
+  }
+  // a degenerate triangle (NaN normal) never hits in the reference; make it fail test (a)
+  bool bad = false;
+  for (int q = 0; q < 27; ++q) bad = bad || !isfinite(o[q]);
+  if (bad) {
+    for (int q = 0; q < 27; ++q) o[q] = 0.f;
+    if (nn.x != nn.x || nn.y != nn.y || nn.z != nn.z) o[4] = -1.0f;  // n.d = 0 <= -1 is false: rejected
+    // otherwise (overflow): zeros pass every test and the pair is decided in FP64
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // top-level tests against spheres, bounding spheres and lights (FP64, list order)
 // ---------------------------------------------------------------------------------------
@@ -355,21 +431,88 @@ __device__ inline int first_sphere_like(const SceneDev& sc, d3 o, d3 d) {
   return -1;
 }
 
-// FP64 scan of a triangle index range for the first hit in order (reference order).  Used
-// for secondary rays against top-level triangle runs.
-__device__ inline long long first_tri_exact(const SceneDev& sc, long long first, long long count, d3 o, d3 d,
-                                            double* t, d3* P) {
-  for (long long i = first; i < first + count; ++i) {
-    const rtmi_triangle& tr = sc.tris[i];
-    if (rtx::tri_hit(rtx::ld3(tr.v[0]), rtx::ld3(tr.v[1]), rtx::ld3(tr.v[2]), sc.planes[i], o, d, t, P)) return i;
+// First hit in list order of a general-origin ray among the top-level ordinals [lo, hi): the
+// lane = ray brute-force scan with the three-stage filter prepared by k_pack_general.  Called
+// from divergent shading code: the wave-level votes below only see the lanes that are tracing.
+__device__ inline long long first_tri_filtered(const SceneDev& sc, int lo, int hi, d3 o, d3 d, double* t_out,
+                                               d3* P_out, unsigned long long* n_tests) {
+  const float ox = (float)(o.x - sc.c0[0]), oy = (float)(o.y - sc.c0[1]), oz = (float)(o.z - sc.c0[2]);
+  float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
+  const float ndo = -(dx * ox + dy * oy + dz * oz);
+  const float noo = -(ox * ox + oy * oy + oz * oz);
+  const float o2x = 2.0f * ox, o2y = 2.0f * oy, o2z = 2.0f * oz;
+  // o x d for the edge tests
+  const float mx_ = oy * dz - oz * dy, my_ = oz * dx - ox * dz, mz_ = ox * dy - oy * dx;
+  long long found = -1;
+  const f2* sph = reinterpret_cast<const f2*>(sc.gsph);
+  const int b0 = lo / GSPH_BATCH, b1 = (hi + GSPH_BATCH - 1) / GSPH_BATCH;
+  for (int b = b0; b < b1; ++b) {
+    const f2* p = sph + (size_t)b * 8;
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      const f2 cx = p[pr * 4 + 0], cy = p[pr * 4 + 1], cz = p[pr * 4 + 2], nk = p[pr * 4 + 3];
+      f2 X = {dx, dx}, Y = {dy, dy}, Z = {dz, dz}, N0 = {ndo, ndo};
+      f2 A = __builtin_elementwise_fma(cz, Z, __builtin_elementwise_fma(cy, Y, __builtin_elementwise_fma(cx, X, N0)));
+      f2 OX = {o2x, o2x}, OY = {o2y, o2y}, OZ = {o2z, o2z}, N1 = {noo, noo};
+      f2 B = __builtin_elementwise_fma(cz, OZ, __builtin_elementwise_fma(cy, OY, __builtin_elementwise_fma(cx, OX, N1)));
+      f2 U = __builtin_elementwise_fma(A, A, B) + nk;
+      mx = __builtin_fmaxf(__builtin_fmaxf(mx, U.x), U.y);
+    }
+    if (__builtin_expect(__any(mx >= 0.0f), 0)) {
+      for (int j = 0; j < GSPH_BATCH; ++j) {
+        const int g = b * GSPH_BATCH + j;
+        if (g < lo) continue;
+        if (g >= hi) break;
+        const float* q = reinterpret_cast<const float*>(p) + (j >> 1) * 8 + (j & 1);
+        const float cx = q[0], cy = q[2], cz = q[4], nk = q[6];
+        float A = __builtin_fmaf(cz, dz, __builtin_fmaf(cy, dy, __builtin_fmaf(cx, dx, ndo)));
+        float B = __builtin_fmaf(cz, o2z, __builtin_fmaf(cy, o2y, __builtin_fmaf(cx, o2x, noo)));
+        float U = __builtin_fmaf(A, A, B) + nk;
+        bool cand = !(U < 0.0f) && found < 0;  // NaN (finished ray) is excluded by found < 0
+        if (!__any(cand)) continue;
+        const float* s2 = sc.gst2 + (size_t)g * GST2_FLOATS;
+        {
+          const float nx = s2[0], ny = s2[1], nz = s2[2], cpl = s2[3], Ea = s2[4], Eb = s2[5];
+          float nd = __builtin_fmaf(nz, dz, __builtin_fmaf(ny, dy, nx * dx));
+          float no = __builtin_fmaf(nz, oz, __builtin_fmaf(ny, oy, nx * ox)) - cpl;
+          cand = cand && (nd <= Ea) && (no >= -Eb);
+        }
+        if (!__any(cand)) continue;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+          const float* w = s2 + 9 + e * 6;
+          float sv = __builtin_fmaf(w[2], dz, __builtin_fmaf(w[1], dy, w[0] * dx));
+          sv = __builtin_fmaf(w[5], mz_, __builtin_fmaf(w[4], my_, __builtin_fmaf(w[3], mx_, sv)));
+          cand = cand && (sv <= s2[6 + e]);
+        }
+        if (!__any(cand)) continue;
+        if (cand) {
+          const int ti = sc.top_group[g];
+          const rtmi_triangle& tr = sc.tris[ti];
+          double t;
+          d3 P;
+          if (rtx::tri_hit(rtx::ld3(tr.v[0]), rtx::ld3(tr.v[1]), rtx::ld3(tr.v[2]), sc.planes[ti], o, d, &t, &P)) {
+            found = ti;
+            *t_out = t;
+            *P_out = P;
+            *n_tests += (unsigned long long)(g - lo + 1);  // list positions this ray consumed
+            dx = dy = dz = __builtin_nanf("");  // this ray nominates nothing from here on
+          }
+        }
+      }
+      if (__all(found >= 0)) break;
+    }
   }
-  return -1;
+  if (found < 0) *n_tests += (unsigned long long)(hi - lo);
+  return found;
 }
 
 // traceRay over the whole top-level list (RayTracingFunctions.swift:37-44) for a secondary
 // ray: intersections[0] if want_first, and whether any non-bounding object is hit.
+template <bool HAS_TOP>
 __device__ inline bool trace_top_secondary(const SceneDev& sc, d3 o, d3 d, bool want_first, Hit* h,
-                                           bool* any_non_bounding) {
+                                           bool* any_non_bounding, unsigned long long* n_tests) {
   bool found = false, anb = false;
   for (int k = 0; k < sc.n_objects; ++k) {
     if (want_first ? found : anb) break;
@@ -389,10 +532,11 @@ __device__ inline bool trace_top_secondary(const SceneDev& sc, d3 o, d3 d, bool 
       } else if (ob.kind == RTMI_SPHERE) {
         if (rtx::sphere_any(rtx::ld3(ob.center), ob.radius, o, d)) anb = true;
       }
-    } else if (ob.kind == RTMI_TRIANGLES) {
+    } else if (HAS_TOP && ob.kind == RTMI_TRIANGLES) {
       double t;
       d3 P;
-      long long i = first_tri_exact(sc, ob.first, ob.count, o, d, &t, &P);
+      const int lo = sc.run_start[k];
+      long long i = first_tri_filtered(sc, lo, lo + (int)ob.count, o, d, &t, &P, n_tests);
       if (i >= 0) {
         anb = true;
         if (!found) {
@@ -757,6 +901,12 @@ struct RGBd {
   double r, g, b;
 };
 
+// the two frame constants shading reads
+struct ShadeConst {
+  double cam[3];
+  double ambient[3];
+};
+
 // pow(base, exponent) of the specular term (RayTracingFunctions.swift:259), base in (0, 1].
 // For the usual small whole-number exponents (OBJ "Ns" values like 8) binary powering is used:
 // at most ceil(log2 n)+popcount roundings, i.e. a few ulp, far below what can change
@@ -797,9 +947,10 @@ __device__ inline int count_facing_lights(const SceneDev& sc, d3 P, d3 n, bool n
   return c;
 }
 
-template <bool REFLECT>
-__device__ RGBd calculate_lighting(const SceneDev& sc, const FrameConst& fc, const Hit& is, d3 camera,
-                                   unsigned long long* n_refl, unsigned long long* n_shadow) {
+template <bool REFLECT, bool HAS_TOP>
+__device__ RGBd calculate_lighting(const SceneDev& sc, const ShadeConst& fc, const Hit& is, d3 camera,
+                                   unsigned long long* n_refl, unsigned long long* n_shadow,
+                                   unsigned long long* n_tests, unsigned long long* n_elided) {
   d3 surface_point = is.P;
   RGBd I = {0.0, 0.0, 0.0};
   const bool has_material = is.material >= 0;
@@ -814,7 +965,9 @@ __device__ RGBd calculate_lighting(const SceneDev& sc, const FrameConst& fc, con
   if (!is.has_normal) return I;  // RTF:199-202
   if (!REFLECT && !has_material) {
     // nothing below can change I (= 0); only the shadow rays are counted
-    *n_shadow += count_facing_lights(sc, surface_point, is.n, is.n_unit);
+    int c = count_facing_lights(sc, surface_point, is.n, is.n_unit);
+    *n_shadow += c;
+    *n_elided += c;
     return I;
   }
   d3 normal = is.n;
@@ -829,8 +982,8 @@ __device__ RGBd calculate_lighting(const SceneDev& sc, const FrameConst& fc, con
     Hit rh;
     bool anb;
     *n_refl += 1;
-    if (trace_top_secondary(sc, surface_point, reflection, true, &rh, &anb)) {
-      contribution = calculate_lighting<false>(sc, fc, rh, surface_point, n_refl, n_shadow);
+    if (trace_top_secondary<HAS_TOP>(sc, surface_point, reflection, true, &rh, &anb, n_tests)) {
+      contribution = calculate_lighting<false, HAS_TOP>(sc, fc, rh, surface_point, n_refl, n_shadow, n_tests, n_elided);
     }
     I.r = I.r + contribution.r;
     I.g = I.g + contribution.g;
@@ -838,7 +991,9 @@ __device__ RGBd calculate_lighting(const SceneDev& sc, const FrameConst& fc, con
   }
 
   if (!has_material) {  // the light loop adds nothing (RTF:245); count its shadow rays
-    *n_shadow += count_facing_lights(sc, surface_point, normal, true);
+    int c = count_facing_lights(sc, surface_point, normal, true);
+    *n_shadow += c;
+    *n_elided += c;
     I.r = rtx::clamp01(I.r); I.g = rtx::clamp01(I.g); I.b = rtx::clamp01(I.b);  // RTF:269
     return I;
   }
@@ -850,7 +1005,7 @@ __device__ RGBd calculate_lighting(const SceneDev& sc, const FrameConst& fc, con
     Hit dummy;
     bool anb = false;
     *n_shadow += 1;
-    trace_top_secondary(sc, surface_point, point_to_light, false, &dummy, &anb);
+    trace_top_secondary<HAS_TOP>(sc, surface_point, point_to_light, false, &dummy, &anb, n_tests);
     if (anb) continue;           // RTF:241
     if (!has_material) continue; // RTF:245
     double lr = light.diffuse[0], lg = light.diffuse[1], lb = light.diffuse[2];
@@ -871,12 +1026,15 @@ __device__ RGBd calculate_lighting(const SceneDev& sc, const FrameConst& fc, con
   return I;
 }
 
+// HAS_TOP: the scene lists triangles at top level, so secondary rays scan them (the code of
+// that scan is left out of the instantiation for scenes without such runs).
+template <bool HAS_TOP>
 __global__ void __launch_bounds__(256)
-k_shade(FrameConst fc, SceneDev sc, const double* __restrict__ dirs, const double* __restrict__ tval,
-        const int* __restrict__ q_shade,
+k_shade(ShadeConst fc, SceneDev sc, const double* __restrict__ dirs,
+        const double* __restrict__ tval, const int* __restrict__ q_shade,
         const int* __restrict__ nq_ptr, const int* __restrict__ hit_id, double* rgb, DevCounters* cnt) {
   int q = blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned long long n_refl = 0, n_shadow = 0, n_hit = 0;
+  unsigned long long n_refl = 0, n_shadow = 0, n_hit = 0, n_tests = 0, n_elided = 0;
   if (q < *nq_ptr) {
     int s = q_shade[q];
     d3 d = rtx::mk(dirs[(size_t)s * 3 + 0], dirs[(size_t)s * 3 + 1], dirs[(size_t)s * 3 + 2]);
@@ -915,7 +1073,7 @@ k_shade(FrameConst fc, SceneDev sc, const double* __restrict__ dirs, const doubl
     RGBd c = {0.0, 0.0, 0.0};
     if (ok) {
       n_hit = 1;
-      c = calculate_lighting<true>(sc, fc, h, cam, &n_refl, &n_shadow);
+      c = calculate_lighting<true, HAS_TOP>(sc, fc, h, cam, &n_refl, &n_shadow, &n_tests, &n_elided);
     }
     rgb[(size_t)s * 3 + 0] = c.r;
     rgb[(size_t)s * 3 + 1] = c.g;
@@ -924,6 +1082,8 @@ k_shade(FrameConst fc, SceneDev sc, const double* __restrict__ dirs, const doubl
   wave_count(cnt, C_HITS, n_hit);
   wave_count(cnt, C_REFL, n_refl);
   wave_count(cnt, C_SHADOW, n_shadow);
+  wave_count(cnt, C_TESTS_SECONDARY, n_tests);
+  wave_count(cnt, C_SHADOW_ELIDED, n_elided);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -988,6 +1148,9 @@ struct rtmi_scene {
   rtmi_triangle* d_tris = nullptr;
   TriPlane* d_planes = nullptr;
   int* d_tri_owner = nullptr;
+  float* d_gsph = nullptr;      // general-origin filter of the top-level runs
+  float* d_gst2 = nullptr;
+  int* d_run_start = nullptr;
   std::vector<TriGroup> groups;  // [0] = top-level runs (may be empty), then bounding objects
   SceneDev dev{};
   // per-batch work buffers, grown on demand
@@ -1002,6 +1165,7 @@ struct rtmi_scene {
   double* d_tval = nullptr;
   FrameConst* d_fc = nullptr;
   FrameConst h_fc{};
+  SceneDev* d_scdev = nullptr;       // device copy of `dev` for kernels that take it by pointer
   std::vector<SearchArgs> h_sargs;   // one argument block per triangle group
   SearchArgs* d_sargs = nullptr;
   double* d_tabs = nullptr;  // utab then vtab
@@ -1125,9 +1289,10 @@ extern "C" void rtmi_scene_destroy(rtmi_scene* sc) {
   }
   (void)hipFree(sc->d_objects); (void)hipFree(sc->d_lights); (void)hipFree(sc->d_materials);
   (void)hipFree(sc->d_tris); (void)hipFree(sc->d_planes); (void)hipFree(sc->d_tri_owner);
+  (void)hipFree(sc->d_gsph); (void)hipFree(sc->d_gst2); (void)hipFree(sc->d_run_start);
   (void)hipFree(sc->d_hit_id); (void)hipFree(sc->d_tri_hit); (void)hipFree(sc->d_q_child);
   (void)hipFree(sc->d_q_shade); (void)hipFree(sc->d_q_top); (void)hipFree(sc->d_rgb);
-  (void)hipFree(sc->d_dirs); (void)hipFree(sc->d_tval); (void)hipFree(sc->d_fc); (void)hipFree(sc->d_tabs); (void)hipFree(sc->d_sargs);
+  (void)hipFree(sc->d_dirs); (void)hipFree(sc->d_tval); (void)hipFree(sc->d_fc); (void)hipFree(sc->d_tabs); (void)hipFree(sc->d_sargs); (void)hipFree(sc->d_scdev);
   (void)hipFree(sc->d_blocks); (void)hipFree(sc->d_cnt);
   if (sc->ev_a) (void)hipEventDestroy(sc->ev_a);
   if (sc->ev_b) (void)hipEventDestroy(sc->ev_b);
@@ -1221,6 +1386,43 @@ static int32_t scene_create_impl(const rtmi_scene_desc* desc, int32_t device, rt
     hipLaunchKernelGGL(k_tri_planes, dim3(nb), dim3(256), 0, sc->stream, sc->d_tris, (long long)desc->n_triangles, sc->d_planes);
     HIP_TRY(hipGetLastError());
   }
+  // general-origin filter for secondary rays against the top-level triangle runs
+  double c0[3] = {0.0, 0.0, 0.0};
+  if (!top.empty()) {
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    double slo[3] = {INFINITY, INFINITY, INFINITY}, shi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    auto grow = [](double* l, double* h, const double* p, double r) {
+      for (int a = 0; a < 3; ++a) { l[a] = std::min(l[a], p[a] - r); h[a] = std::max(h[a], p[a] + r); }
+    };
+    for (int ti : top) for (int k = 0; k < 3; ++k) grow(lo, hi, desc->triangles[ti].v[k], 0.0);
+    // every surface a ray can start from: all triangles, spheres, lights listed as objects
+    for (int64_t i = 0; i < desc->n_triangles; ++i) for (int k = 0; k < 3; ++k) grow(slo, shi, desc->triangles[i].v[k], 0.0);
+    for (int64_t k = 0; k < desc->n_objects; ++k) {
+      const rtmi_object& ob = desc->objects[k];
+      if (ob.kind == RTMI_SPHERE || ob.kind == RTMI_BOUNDING_SPHERE) grow(slo, shi, ob.center, fabs(ob.radius));
+      else if (ob.kind == RTMI_LIGHT) grow(slo, shi, desc->lights[ob.first].loc, 0.0);
+    }
+    double r_o1 = 0.0;
+    for (int a = 0; a < 3; ++a) {
+      c0[a] = 0.5 * (lo[a] + hi[a]);
+      r_o1 += std::max(fabs(slo[a] - c0[a]), fabs(shi[a] - c0[a]));
+    }
+    r_o1 *= 1.01;
+    if (!std::isfinite(r_o1)) r_o1 = 0.0;  // the filter then degrades to "always nominate" via its own checks
+    std::vector<int> run_start((size_t)desc->n_objects, 0);
+    int ord = 0;
+    for (int64_t k = 0; k < desc->n_objects; ++k)
+      if (desc->objects[k].kind == RTMI_TRIANGLES) { run_start[k] = ord; ord += (int)desc->objects[k].count; }
+    if ((rc = upload((void**)&sc->d_run_start, run_start.data(), sizeof(int) * run_start.size()))) return rc;
+    const size_t nt = top.size();
+    const size_t sph_floats = 16 * ((nt + GSPH_BATCH - 1) / GSPH_BATCH + 1);
+    HIP_TRY(hipMalloc(&sc->d_gsph, sizeof(float) * sph_floats));
+    HIP_TRY(hipMemset(sc->d_gsph, 0, sizeof(float) * sph_floats));  // padding triangles: T + 0 - |c|^2.. see below
+    HIP_TRY(hipMalloc(&sc->d_gst2, sizeof(float) * GST2_FLOATS * nt));
+    hipLaunchKernelGGL(k_pack_general, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, sc->stream, sc->d_tris,
+                       sc->groups[0].d_group, (int)nt, rtx::mk(c0[0], c0[1], c0[2]), r_o1, sc->d_gsph, sc->d_gst2);
+    HIP_TRY(hipGetLastError());
+  }
   HIP_TRY(hipMalloc(&sc->d_cnt, sizeof(DevCounters)));
   HIP_TRY(hipMalloc(&sc->d_fc, sizeof(FrameConst)));
   sc->h_sargs.resize(sc->groups.size());
@@ -1236,6 +1438,13 @@ static int32_t scene_create_impl(const rtmi_scene_desc* desc, int32_t device, rt
   sc->dev.n_lights = desc->n_lights;
   sc->dev.n_sphere_like = n_sphere_like;
   sc->dev.n_top_tris = (long long)top.size();
+  sc->dev.gsph = sc->d_gsph;
+  sc->dev.gst2 = sc->d_gst2;
+  sc->dev.top_group = sc->groups[0].d_group;
+  sc->dev.run_start = sc->d_run_start;
+  for (int a = 0; a < 3; ++a) sc->dev.c0[a] = c0[a];
+  HIP_TRY(hipMalloc(&sc->d_scdev, sizeof(SceneDev)));
+  HIP_TRY(hipMemcpy(sc->d_scdev, &sc->dev, sizeof(SceneDev), hipMemcpyHostToDevice));
   return RTMI_OK;
 }
 
@@ -1452,6 +1661,9 @@ static int32_t render_impl(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_pa
   }
   HIP_TRY(hipMemcpyAsync(sc->d_sargs, sc->h_sargs.data(), sizeof(SearchArgs) * sc->groups.size(), hipMemcpyHostToDevice, st));
 
+  ShadeConst shc;
+  for (int a = 0; a < 3; ++a) { shc.cam[a] = fc.cam[a]; shc.ambient[a] = fc.ambient[a]; }
+
   float ms_search = 0.f, ms_primary = 0.f;
   long long launches = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;
@@ -1489,7 +1701,7 @@ static int32_t render_impl(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_pa
       timed.emplace_back(e0, e1);
       ++launches;
     }
-    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(256), 0, st, fc, sc->dev, sc->d_dirs, sc->d_tval, sc->d_q_shade, &sc->d_cnt->q_shade,
+    hipLaunchKernelGGL(sc->groups[0].n > 0 ? k_shade<true> : k_shade<false>, dim3(grid), dim3(256), 0, st, shc, sc->dev, sc->d_dirs, sc->d_tval, sc->d_q_shade, &sc->d_cnt->q_shade,
                        sc->d_hit_id, sc->d_rgb, sc->d_cnt);
     int npix = (int)(nb * BLK_PIX);
     hipLaunchKernelGGL(k_resolve, dim3((npix + 255) / 256), dim3(256), 0, st, fc, d_blk, npix, sc->d_hit_id, sc->d_rgb,
@@ -1519,11 +1731,12 @@ static int32_t render_impl(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_pa
     counters->samples = live_samples;
     counters->rays_reflection = (int64_t)sum[C_REFL];
     counters->rays_shadow = (int64_t)sum[C_SHADOW];
-    // secondary rays: the reference tests every top-level object (RayTracingFunctions.swift:41-43)
-    counters->tri_tests = (int64_t)sum[C_TESTS_PRIMARY] + secondary * sc->dev.n_top_tris;
+    // pairs actually evaluated: a ray stops counting at its hit
+    counters->tri_tests = (int64_t)(sum[C_TESTS_PRIMARY] + sum[C_TESTS_SECONDARY]);
     counters->sphere_tests = (live_samples + secondary) * sc->dev.n_sphere_like;
     counters->tri_exact_tests = (int64_t)sum[C_EXACT];
     counters->primary_hits = (int64_t)sum[C_HITS];
+    counters->shadow_rays_elided = (int64_t)sum[C_SHADOW_ELIDED];
     counters->ms_total = ms_total;
     counters->ms_tri_search = ms_search;
     counters->tri_search_launches = launches;

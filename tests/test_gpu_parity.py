@@ -74,6 +74,28 @@ def test_toplevel_triangles_with_shadow_and_reflection(oracle_mod, rt):
     assert o["rays_shadow"] > 0 and o["rays_reflection"] == o["primary_hits"]
 
 
+def test_toplevel_mesh_5120_triangles_secondary_ray_filter(oracle_mod, rt):
+    """Form T at the stand-in mesh size: reflection and shadow rays scan the top-level triangles
+    through the general-origin filter (sphere, plane/edge, FP64); also with a shuffled list."""
+    cam = scenes.make_camera(**scenes.MESH_CAMERA)
+    for seed in (None, 3):
+        data = scenes.mesh_scene(4, "T", 3, shuffle_seed=seed)
+        o, g = assert_parity(oracle_mod, rt, data, cam, scenes.make_params(200, 160, 0.5))
+        assert o["rays_shadow"] > 0 and g["tri_tests"] > g["tri_tests_primary_kernel"] > 0
+
+
+def test_toplevel_mesh_far_from_origin(oracle_mod, rt):
+    """Form T with coordinates of order 1e5 (FP32 filter margins scale with the scene extent)."""
+    v, f = scenes.displaced_icosphere(2)
+    tris = scenes.triangles_from_vertices(v * 2.0e4 + np.array([3.0e5, -1.0e5, 2.0e5]), f, 0)
+    data = scenes.SceneData(lights=np.concatenate([scenes.light(loc=(4.0e5, 0.0, 4.0e5), specular=(0.8,) * 3, diffuse=(0.5,) * 3),
+                                                   scenes.light(loc=(2.0e5, 3.0e5, 3.0e5), specular=(0.8,) * 3, diffuse=(0.5,) * 3)]),
+                            materials=scenes.material(**scenes.VC_MATERIAL),
+                            objects=scenes.triangles_object(0, len(tris)), triangles=tris)
+    cam = scenes.make_camera((3.0e5, -1.0e5, 2.0e5 + 8.0e4), (0, 0, -1), 10.0)
+    assert_parity(oracle_mod, rt, data, cam, scenes.make_params(96, 96, 0.5))
+
+
 def test_shuffled_triangle_order_list_order_semantics(oracle_mod, rt):
     # shuffling makes "first in list order" differ from "nearest" on the non-convex mesh
     data = scenes.mesh_scene(3, "B", 1, shuffle_seed=0, bounding_sphere=rt.bounding_sphere)
