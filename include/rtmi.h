@@ -194,6 +194,26 @@ int32_t rtmi_render_device(rtmi_scene* scene, const rtmi_camera* camera,
  * stride(from: x, to: x+1, by: s) squared (WorldCoordinateSequence.swift:74-78). */
 int32_t rtmi_samples_per_pixel(double pixel_subdivision);
 
+/* ---- OBJ / MTL ingest (host only) ---------------------------------------------------- */
+
+typedef struct rtmi_obj_mesh rtmi_obj_mesh;
+
+/* readObjFile (ObjLoader.swift:160-201), readMtlFile (:95-158; mtl_path may be NULL) and
+ * createTriangleList (ViewController.swift:107-120) with the reference's parsing rules:
+ * lines split on "\n", tokens on " ", `f` takes plain 1-based integers and keeps the first
+ * three, `usemtl` names the material of the faces that follow, every MTL block needs
+ * Ns, d, illum, Kd, Ka, Ks and its colours are clamped to [0,1] like RGB.init.  Input the
+ * reference would trap on is reported as RTMI_ERR_INVALID_ARGUMENT.  Unlike the reference,
+ * each triangle's material index is set from its face's material name (-1 if unknown). */
+int32_t rtmi_obj_load(const char* obj_path, const char* mtl_path, rtmi_obj_mesh** out);
+void rtmi_obj_free(rtmi_obj_mesh* mesh);
+int64_t rtmi_obj_vertex_count(const rtmi_obj_mesh* mesh);
+int64_t rtmi_obj_triangle_count(const rtmi_obj_mesh* mesh);
+const rtmi_triangle* rtmi_obj_triangles(const rtmi_obj_mesh* mesh);   /* owned by the mesh */
+int32_t rtmi_obj_material_count(const rtmi_obj_mesh* mesh);
+const rtmi_material* rtmi_obj_materials(const rtmi_obj_mesh* mesh);   /* owned by the mesh */
+const char* rtmi_obj_material_name(const rtmi_obj_mesh* mesh, int32_t index);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,6 +52,21 @@ def lib():
         L.rtmi_render_device.restype = C.c_int32
         L.rtmi_render_device.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Params),
                                          C.c_void_p, C.c_void_p, C.POINTER(Counters)]
+        L.rtmi_obj_load.restype = C.c_int32
+        L.rtmi_obj_load.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]
+        L.rtmi_obj_free.restype = None
+        L.rtmi_obj_free.argtypes = [C.c_void_p]
+        for name in ("rtmi_obj_vertex_count", "rtmi_obj_triangle_count"):
+            getattr(L, name).restype = C.c_int64
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.rtmi_obj_material_count.restype = C.c_int32
+        L.rtmi_obj_material_count.argtypes = [C.c_void_p]
+        L.rtmi_obj_triangles.restype = C.c_void_p
+        L.rtmi_obj_triangles.argtypes = [C.c_void_p]
+        L.rtmi_obj_materials.restype = C.c_void_p
+        L.rtmi_obj_materials.argtypes = [C.c_void_p]
+        L.rtmi_obj_material_name.restype = C.c_char_p
+        L.rtmi_obj_material_name.argtypes = [C.c_void_p, C.c_int32]
         if L.rtmi_abi_version() != _abi.RTMI_ABI_VERSION:
             raise ImportError("librtmi.so ABI version does not match raytracer_amd/_abi.py")
         _lib = L
@@ -78,6 +93,27 @@ def bounding_sphere(triangles: np.ndarray):
     tri = np.ascontiguousarray(triangles)
     _check(lib().rtmi_bounding_sphere(tri.ctypes.data, len(tri), c, C.byref(r)), "rtmi_bounding_sphere")
     return tuple(c), r.value
+
+
+def load_obj(obj_path, mtl_path=None):
+    """readObjFile + readMtlFile + createTriangleList with the reference's parsing rules.
+    Returns (triangles TRI_DTYPE array, materials MAT_DTYPE array, material names, vertex count)."""
+    h = C.c_void_p()
+    rc = lib().rtmi_obj_load(os.fsencode(obj_path), os.fsencode(mtl_path) if mtl_path else None, C.byref(h))
+    _check(rc, "rtmi_obj_load")
+    try:
+        L = lib()
+        nt, nm = L.rtmi_obj_triangle_count(h), L.rtmi_obj_material_count(h)
+        tris = np.zeros(nt, scenes.TRI_DTYPE)
+        if nt:
+            C.memmove(tris.ctypes.data, L.rtmi_obj_triangles(h), nt * scenes.TRI_DTYPE.itemsize)
+        mats = np.zeros(nm, scenes.MAT_DTYPE)
+        if nm:
+            C.memmove(mats.ctypes.data, L.rtmi_obj_materials(h), nm * scenes.MAT_DTYPE.itemsize)
+        names = [L.rtmi_obj_material_name(h, i).decode() for i in range(nm)]
+        return tris, mats, names, L.rtmi_obj_vertex_count(h)
+    finally:
+        lib().rtmi_obj_free(h)
 
 
 class Scene:

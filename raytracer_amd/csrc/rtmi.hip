@@ -41,6 +41,8 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 // ---------------------------------------------------------------------------------------
 static thread_local std::string g_last_error;
 
+void rtmi_set_last_error(const std::string& msg) { g_last_error = msg; }  // used by rtmi_obj.cpp
+
 #define HIP_TRY(expr)                                                                      \
   do {                                                                                     \
     hipError_t e_ = (expr);                                                                \
