@@ -84,7 +84,7 @@ def main():
     params = scenes.make_params(W, H, sub)
     my_params = sharding.tile_params(params, rank, world) if world > 1 else params
     composer = sharding.TileComposer(W, H, rank, world, comm_dev)
-    frame = composer.frame if not args.rehearse_gloo else torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
+    staging = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev) if args.rehearse_gloo else None
     torch.cuda.synchronize()
 
     def camera_for(step):
@@ -96,10 +96,15 @@ def main():
               "exact": 0, "samples": 0}
 
     def step(i, record):
-        cnt = scene.render_device(camera_for(i), my_params, frame.data_ptr())
+        # Frames alternate between two buffers: the gather of frame i (enqueued, asynchronous) overlaps
+        # the rendering of frame i+1 into the other buffer.
+        slot = i & 1
+        composer.wait_slot(slot)
+        target = staging if args.rehearse_gloo else composer.frames[slot]
+        cnt = scene.render_device(camera_for(i), my_params, target.data_ptr())
         if args.rehearse_gloo:
-            composer.frame.copy_(frame)
-        composer.compose()  # rank 0 ends the step holding the whole frame
+            composer.frames[slot].copy_(staging)
+        composer.compose(slot)  # rank 0 receives every rank's tiles of this frame
         if record:
             totals["rays"] += cnt["samples"] + cnt["rays_reflection"] + cnt["rays_shadow"]
             totals["samples"] += cnt["samples"]
@@ -134,7 +139,8 @@ def main():
         alone = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
         torch.cuda.synchronize()
         scene.render_device(camera_for(args.warmup + args.steps - 1), params, alone.data_ptr())
-        verified = bool((alone.cpu() == composer.frame.cpu()).all())
+        last = composer.frames[(args.warmup + args.steps - 1) & 1]
+        verified = bool((alone.cpu() == last.cpu()).all())
         assert verified, "the composed multi-rank frame differs from the single-GPU frame"
 
     agg = torch.tensor([float(totals["rays"]), float(totals["tests"]), elapsed], dtype=torch.float64, device=comm_dev)

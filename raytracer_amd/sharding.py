@@ -60,35 +60,58 @@ def broadcast_scene(data, src: int = 0, device="cpu", group=None):
 class TileComposer:
     """Collects the per-rank tiles of a frame on rank 0.
 
-    Every rank owns `frame`, an [H, W, 4] uint8 tensor that its renderer writes its tiles into.
-    `compose()` packs the rank's own pixels (as one int32 per RGBA pixel), gathers the packs on
-    rank 0 and scatters them into rank 0's frame.  Index tensors are built once.
+    Every rank owns `frames`, two [H, W, 4] uint8 tensors that its renderer writes its tiles
+    into alternately.  `compose(slot)` packs the rank's own pixels of frames[slot] (one int32
+    per RGBA pixel), gathers the packs on rank 0 and scatters them into rank 0's frames[slot].
+    All of it is enqueued asynchronously, so the caller can render the next frame into the other
+    slot while this one travels; `wait_slot(slot)` must be called before a slot is rendered into
+    again.  Index tensors are built once.
     """
 
     def __init__(self, width, height, rank, world, device, tile_size=TILE, group=None):
         self.rank, self.world, self.group = rank, world, group
-        self.frame = torch.zeros((height, width, 4), dtype=torch.uint8, device=device)
-        self._flat = self.frame.view(torch.int32).view(-1)  # one element per pixel
+        self.device = torch.device(device)
+        self.frames = [torch.zeros((height, width, 4), dtype=torch.uint8, device=device) for _ in range(2)]
+        self.frame = self.frames[0]
+        self._flat = [f.view(torch.int32).view(-1) for f in self.frames]  # one element per pixel
+        self._packed = [None, None]  # CUDA event per slot: own pixels have been read out
+        if world == 1:
+            return
         idx = [np.flatnonzero(owned_pixel_mask(width, height, r, world, tile_size).ravel()) for r in range(world)]
         self.counts = [len(i) for i in idx]
-        self.maxn = max(self.counts) if idx else 0
+        self.maxn = max(self.counts)
         self._own_idx = torch.from_numpy(idx[rank]).to(device)
-        self._send = torch.zeros(self.maxn, dtype=torch.int32, device=device)
+        self._send = [torch.zeros(self.maxn, dtype=torch.int32, device=device) for _ in range(2)]
         if rank == 0:
-            self._recv = torch.zeros((world, self.maxn), dtype=torch.int32, device=device)
-            # peers' pixels only (rank 0's own tiles are already in its frame)
-            self._peer_idx = [torch.from_numpy(idx[r]).to(device) for r in range(world)]
+            self._recv = [torch.zeros((world, self.maxn), dtype=torch.int32, device=device) for _ in range(2)]
+            # one scatter for all peers: positions of the valid entries of recv[1:] and their pixel indices
+            src = np.concatenate([r * self.maxn + np.arange(self.counts[r]) for r in range(1, world)])
+            dst = np.concatenate([idx[r] for r in range(1, world)])
+            self._peer_src = torch.from_numpy(src).to(device)
+            self._peer_dst = torch.from_numpy(dst).to(device)
 
-    def compose(self):
-        """Returns rank 0's frame with every rank's tiles in place (None on other ranks)."""
+    def wait_slot(self, slot):
+        """Block until the previous compose() of `slot` has read the rank's pixels out of it."""
+        ev = self._packed[slot]
+        if ev is not None:
+            ev.synchronize()
+
+    def compose(self, slot=0):
+        """Enqueue the gather of frames[slot]; returns rank 0's frame tensor (None on other ranks).
+        The result is complete once the device (and the process group) has drained."""
         if self.world == 1:
-            return self.frame
+            return self.frames[slot]
         n = self.counts[self.rank]
-        torch.index_select(self._flat, 0, self._own_idx, out=self._send[:n])
+        send = self._send[slot]
+        torch.index_select(self._flat[slot], 0, self._own_idx, out=send[:n])
+        if self.device.type == "cuda":
+            ev = torch.cuda.Event()
+            ev.record()
+            self._packed[slot] = ev
         if self.rank == 0:
-            dist.gather(self._send, list(self._recv.unbind(0)), dst=0, group=self.group)
-            for r in range(1, self.world):
-                self._flat.index_copy_(0, self._peer_idx[r], self._recv[r, : self.counts[r]])
-            return self.frame
-        dist.gather(self._send, None, dst=0, group=self.group)
+            recv = self._recv[slot]
+            dist.gather(send, list(recv.unbind(0)), dst=0, group=self.group)
+            self._flat[slot].index_copy_(0, self._peer_dst, recv.view(-1).index_select(0, self._peer_src))
+            return self.frames[slot]
+        dist.gather(send, None, dst=0, group=self.group)
         return None
