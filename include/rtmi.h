@@ -190,6 +190,16 @@ int32_t rtmi_render_device(rtmi_scene* scene, const rtmi_camera* camera,
                            const rtmi_params* params, void* rgba_dev, void* hit_id_dev,
                            rtmi_counters* counters);
 
+/* The same frame in two halves, for callers that have other work to enqueue while the GPU
+ * renders (e.g. the transfer of the previous frame): rtmi_render_begin enqueues every kernel
+ * of the frame on the scene's stream and returns without waiting; rtmi_render_end waits for
+ * that stream and fills `counters` (optional).  One frame may be in flight per scene; camera
+ * and params may be freed after rtmi_render_begin returns.  No counterpart in the reference
+ * (its render call is synchronous, RayTracingFunctions.swift:145-180). */
+int32_t rtmi_render_begin(rtmi_scene* scene, const rtmi_camera* camera, const rtmi_params* params,
+                          void* rgba_dev, void* hit_id_dev);
+int32_t rtmi_render_end(rtmi_scene* scene, rtmi_counters* counters);
+
 /* Number of sub-samples per pixel for a subdivision value: the count of
  * stride(from: x, to: x+1, by: s) squared (WorldCoordinateSequence.swift:74-78). */
 int32_t rtmi_samples_per_pixel(double pixel_subdivision);

@@ -52,6 +52,10 @@ def lib():
         L.rtmi_render_device.restype = C.c_int32
         L.rtmi_render_device.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Params),
                                          C.c_void_p, C.c_void_p, C.POINTER(Counters)]
+        L.rtmi_render_begin.restype = C.c_int32
+        L.rtmi_render_begin.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Params), C.c_void_p, C.c_void_p]
+        L.rtmi_render_end.restype = C.c_int32
+        L.rtmi_render_end.argtypes = [C.c_void_p, C.POINTER(Counters)]
         L.rtmi_obj_load.restype = C.c_int32
         L.rtmi_obj_load.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]
         L.rtmi_obj_free.restype = None
@@ -158,4 +162,16 @@ class Scene:
         rc = lib().rtmi_render_device(self._h, C.byref(camera), C.byref(params), C.c_void_p(rgba_ptr),
                                       C.c_void_p(hit_ptr) if hit_ptr else None, C.byref(cnt))
         _check(rc, "rtmi_render_device")
+        return cnt.as_dict()
+
+    def render_begin(self, camera: Camera, params: Params, rgba_ptr: int, hit_ptr: int = 0):
+        """Enqueue a frame into device buffers and return at once (rtmi_render_begin)."""
+        rc = lib().rtmi_render_begin(self._h, C.byref(camera), C.byref(params), C.c_void_p(rgba_ptr),
+                                     C.c_void_p(hit_ptr) if hit_ptr else None)
+        _check(rc, "rtmi_render_begin")
+
+    def render_end(self):
+        """Wait for the frame in flight; returns its counters dict (rtmi_render_end)."""
+        cnt = Counters()
+        _check(lib().rtmi_render_end(self._h, C.byref(cnt)), "rtmi_render_end")
         return cnt.as_dict()

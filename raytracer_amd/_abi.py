@@ -77,7 +77,7 @@ class Counters(C.Structure):
 EXPORTS = [
     "rtmi_abi_version", "rtmi_status_string", "rtmi_last_error", "rtmi_device_count",
     "rtmi_bounding_sphere", "rtmi_scene_create", "rtmi_scene_destroy", "rtmi_render",
-    "rtmi_render_device", "rtmi_samples_per_pixel",
+    "rtmi_render_device", "rtmi_render_begin", "rtmi_render_end", "rtmi_samples_per_pixel",
     "rtmi_obj_load", "rtmi_obj_free", "rtmi_obj_vertex_count", "rtmi_obj_triangle_count", "rtmi_obj_triangles",
     "rtmi_obj_material_count", "rtmi_obj_materials", "rtmi_obj_material_name",
 ]

@@ -1178,6 +1178,13 @@ struct rtmi_scene {
   std::array<int, 9> blocks_key{};     // frame geometry + tile selection it was built for
   bool blocks_valid = false;
   DevCounters* d_cnt = nullptr;
+  // one frame may be in flight between rtmi_render_begin and rtmi_render_end
+  bool pending = false;
+  DevCounters* h_cnt = nullptr;  // pinned host copy of the device counters
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;  // event pairs around search launches, reused
+  size_t ev_used = 0;
+  long long pend_launches = 0;
+  int64_t pend_live_samples = 0;
   std::mutex mu;
 };
 
@@ -1296,6 +1303,8 @@ extern "C" void rtmi_scene_destroy(rtmi_scene* sc) {
   (void)hipFree(sc->d_q_shade); (void)hipFree(sc->d_q_top); (void)hipFree(sc->d_rgb);
   (void)hipFree(sc->d_dirs); (void)hipFree(sc->d_tval); (void)hipFree(sc->d_fc); (void)hipFree(sc->d_tabs); (void)hipFree(sc->d_sargs); (void)hipFree(sc->d_scdev);
   (void)hipFree(sc->d_blocks); (void)hipFree(sc->d_cnt);
+  if (sc->h_cnt) (void)hipHostFree(sc->h_cnt);
+  for (auto& pr : sc->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   if (sc->ev_a) (void)hipEventDestroy(sc->ev_a);
   if (sc->ev_b) (void)hipEventDestroy(sc->ev_b);
   if (sc->ev_c) (void)hipEventDestroy(sc->ev_c);
@@ -1426,6 +1435,7 @@ static int32_t scene_create_impl(const rtmi_scene_desc* desc, int32_t device, rt
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipMalloc(&sc->d_cnt, sizeof(DevCounters)));
+  HIP_TRY(hipHostMalloc((void**)&sc->h_cnt, sizeof(DevCounters), hipHostMallocDefault));
   HIP_TRY(hipMalloc(&sc->d_fc, sizeof(FrameConst)));
   sc->h_sargs.resize(sc->groups.size());
   HIP_TRY(hipMalloc(&sc->d_sargs, sizeof(SearchArgs) * sc->groups.size()));
@@ -1514,14 +1524,15 @@ static int search_rays_per_lane() {
   static int r = [] {
     const char* e = getenv("RTMI_SEARCH_R");
     int v = e ? atoi(e) : 4;
-    return v == 8 ? 8 : 4;
+    return (v == 8 || v == 2) ? v : 4;
   }();
   return r;
 }
 constexpr size_t MAX_BATCH_SAMPLES = 1u << 28;  // 256 Mi samples per batch (68 B of work buffers per sample)
 
-static int32_t render_impl(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_params* p, void* rgba_dev,
-                           void* hit_dev, rtmi_counters* counters) {
+// Enqueue a whole frame on the scene's stream; nothing here waits for the device.
+static int32_t render_begin_impl(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_params* p, void* rgba_dev,
+                                 void* hit_dev) {
   if (!sc || !cam || !p || !rgba_dev) return RTMI_ERR_INVALID_ARGUMENT;
   if (p->width < 2 || p->height < 2) return RTMI_ERR_INVALID_ARGUMENT;
   if (p->hit_policy != RTMI_HIT_LIST_ORDER) return RTMI_ERR_UNSUPPORTED;
@@ -1537,6 +1548,10 @@ static int32_t render_impl(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_pa
   if (p->tile_world > 1 && p->tile_size <= 0) return RTMI_ERR_INVALID_ARGUMENT;
 
   std::lock_guard<std::mutex> lock(sc->mu);
+  if (sc->pending) {
+    g_last_error = "a frame is already in flight on this scene; call rtmi_render_end first";
+    return RTMI_ERR_INVALID_ARGUMENT;
+  }
   HIP_TRY(hipSetDevice(sc->device));
 
   // camera frame: RayTracingFunctions.swift:156-170, WorldCoordinateSequence.swift:58-59
@@ -1666,9 +1681,20 @@ static int32_t render_impl(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_pa
   ShadeConst shc;
   for (int a = 0; a < 3; ++a) { shc.cam[a] = fc.cam[a]; shc.ambient[a] = fc.ambient[a]; }
 
-  float ms_search = 0.f, ms_primary = 0.f;
   long long launches = 0;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;
+  sc->ev_used = 0;
+  auto next_events = [&](hipEvent_t* e0, hipEvent_t* e1) -> int32_t {
+    if (sc->ev_used == sc->ev_pool.size()) {
+      hipEvent_t a, b;
+      HIP_TRY(hipEventCreate(&a));
+      HIP_TRY(hipEventCreate(&b));
+      sc->ev_pool.emplace_back(a, b);
+    }
+    *e0 = sc->ev_pool[sc->ev_used].first;
+    *e1 = sc->ev_pool[sc->ev_used].second;
+    ++sc->ev_used;
+    return RTMI_OK;
+  };
 
   for (size_t b0 = 0; b0 < blocks.size(); b0 += blocks_per_batch) {
     size_t nb = std::min(blocks_per_batch, blocks.size() - b0);
@@ -1680,15 +1706,14 @@ static int32_t render_impl(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_pa
                        sc->d_q_shade, sc->d_q_top, sc->d_cnt);
     const int SR = search_rays_per_lane();
     const int search_grid = (nsamples + 256 * SR - 1) / (256 * SR);
-    auto search_kernel = SR == 8 ? k_search_primary<8> : k_search_primary<4>;
+    auto search_kernel = SR == 8 ? k_search_primary<8> : (SR == 2 ? k_search_primary<2> : k_search_primary<4>);
     if (sc->groups[0].n > 0) {
       TriGroup& g = sc->groups[0];
       hipEvent_t e0, e1;
-      HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+      if ((rc = next_events(&e0, &e1))) return rc;
       HIP_TRY(hipEventRecord(e0, st));
       hipLaunchKernelGGL(search_kernel, dim3(search_grid), dim3(256), 0, st, sc->d_sargs + 0, (const f2*)g.d_cone);
       HIP_TRY(hipEventRecord(e1, st));
-      timed.emplace_back(e0, e1);
       ++launches;
       hipLaunchKernelGGL(k_resolve_top, dim3(grid), dim3(256), 0, st, sc->dev, sc->d_q_top, &sc->d_cnt->q_top, sc->d_tri_hit,
                          sc->d_tri_owner, sc->d_hit_id, sc->d_q_child, sc->d_q_shade, sc->d_cnt);
@@ -1696,11 +1721,10 @@ static int32_t render_impl(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_pa
     for (size_t gi = 1; gi < sc->groups.size(); ++gi) {
       TriGroup& g = sc->groups[gi];
       hipEvent_t e0, e1;
-      HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+      if ((rc = next_events(&e0, &e1))) return rc;
       HIP_TRY(hipEventRecord(e0, st));
       hipLaunchKernelGGL(search_kernel, dim3(search_grid), dim3(256), 0, st, sc->d_sargs + gi, (const f2*)g.d_cone);
       HIP_TRY(hipEventRecord(e1, st));
-      timed.emplace_back(e0, e1);
       ++launches;
     }
     hipLaunchKernelGGL(sc->groups[0].n > 0 ? k_shade<true> : k_shade<false>, dim3(grid), dim3(256), 0, st, shc, sc->dev, sc->d_dirs, sc->d_tval, sc->d_q_shade, &sc->d_cnt->q_shade,
@@ -1711,20 +1735,34 @@ static int32_t render_impl(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_pa
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipEventRecord(sc->ev_b, st));
-  DevCounters hc;
-  HIP_TRY(hipMemcpyAsync(&hc, sc->d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  float ms_total = 0.f;
-  HIP_TRY(hipEventElapsedTime(&ms_total, sc->ev_a, sc->ev_b));
-  for (auto& pr : timed) {
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
-    ms_search += ms;
-    (void)hipEventDestroy(pr.first);
-    (void)hipEventDestroy(pr.second);
+  HIP_TRY(hipMemcpyAsync(sc->h_cnt, sc->d_cnt, sizeof(DevCounters), hipMemcpyDeviceToHost, st));
+  sc->pend_launches = launches;
+  sc->pend_live_samples = live_samples;
+  sc->pending = true;
+  return RTMI_OK;
+}
+
+// Wait for the frame enqueued by render_begin_impl and report its counters.
+static int32_t render_end_impl(rtmi_scene* sc, rtmi_counters* counters) {
+  if (!sc) return RTMI_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lock(sc->mu);
+  if (!sc->pending) {
+    g_last_error = "no frame in flight on this scene";
+    return RTMI_ERR_INVALID_ARGUMENT;
   }
-  ms_primary = ms_search;
+  sc->pending = false;
+  HIP_TRY(hipSetDevice(sc->device));
+  HIP_TRY(hipStreamSynchronize(sc->stream));
+  const DevCounters& hc = *sc->h_cnt;
+  float ms_total = 0.f, ms_search = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms_total, sc->ev_a, sc->ev_b));
+  for (size_t i = 0; i < sc->ev_used; ++i) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, sc->ev_pool[i].first, sc->ev_pool[i].second));
+    ms_search += ms;
+  }
   if (counters) {
+    const int64_t live_samples = sc->pend_live_samples;
     unsigned long long sum[C_NCOUNTERS] = {0};
     for (int sl = 0; sl < NSLOT; ++sl)
       for (int c = 0; c < C_NCOUNTERS; ++c) sum[c] += hc.slot[sl][c];
@@ -1741,12 +1779,26 @@ static int32_t render_impl(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_pa
     counters->shadow_rays_elided = (int64_t)sum[C_SHADOW_ELIDED];
     counters->ms_total = ms_total;
     counters->ms_tri_search = ms_search;
-    counters->tri_search_launches = launches;
+    counters->tri_search_launches = sc->pend_launches;
     counters->tri_tests_primary_kernel = (int64_t)sum[C_TESTS_PRIMARY];
-    counters->ms_primary_kernel = ms_primary;
+    counters->ms_primary_kernel = ms_search;
   }
   return RTMI_OK;
 }
+
+static int32_t render_impl(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_params* p, void* rgba_dev,
+                           void* hit_dev, rtmi_counters* counters) {
+  int32_t rc = render_begin_impl(sc, cam, p, rgba_dev, hit_dev);
+  if (rc != RTMI_OK) return rc;
+  return render_end_impl(sc, counters);
+}
+
+extern "C" int32_t rtmi_render_begin(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_params* p, void* rgba_dev,
+                                     void* hit_dev) {
+  return render_begin_impl(sc, cam, p, rgba_dev, hit_dev);
+}
+
+extern "C" int32_t rtmi_render_end(rtmi_scene* sc, rtmi_counters* counters) { return render_end_impl(sc, counters); }
 
 extern "C" int32_t rtmi_render_device(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_params* p, void* rgba_dev,
                                       void* hit_dev, rtmi_counters* counters) {
