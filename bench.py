@@ -76,8 +76,24 @@ def main():
 
     W, H, sub, level, n_lights = CONFIGS[args.config]
     data = None
+    mesh_note = "stand-in (no pig OBJ available offline)"
     if rank == 0:
-        data = scenes.mesh_scene(level, args.form, n_lights, bounding_sphere=rt.bounding_sphere)
+        pig = os.environ.get("RTMI_PIG_OBJ")
+        if pig and args.config != "C4":
+            # a real mesh, if one is supplied on the box: triangulated, vertex-index-only OBJ (the
+            # reference's parser accepts nothing else); same wrapper, lights and material as the stand-in
+            tris, _, _, _ = rt.load_obj(pig)
+            tris["material"] = 0
+            data = scenes.mesh_scene(0, args.form, n_lights, bounding_sphere=rt.bounding_sphere)
+            data.triangles = tris
+            if args.form == "B":
+                c, r = rt.bounding_sphere(tris)
+                data.objects = scenes.sphere_object(c, r, -1, bounding=True, first=0, count=len(tris))
+            else:
+                data.objects = scenes.triangles_object(0, len(tris))
+            mesh_note = f"real OBJ {os.path.basename(pig)} ({len(tris)} triangles)"
+        else:
+            data = scenes.mesh_scene(level, args.form, n_lights, bounding_sphere=rt.bounding_sphere)
     if world > 1:
         data = sharding.broadcast_scene(data, 0, device=comm_dev)  # RCCL byte broadcast, once
     scene = rt.Scene(data, device=local_rank)
@@ -186,11 +202,11 @@ def main():
             "dtype": "f32 filter + f64 decision",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.config}: stand-in pig mesh (displaced icosphere level {level}, "
-                            f"{len(data.triangles)} triangles), {W}x{H}, {scene_spp(sub)} spp, {n_lights} lights, "
+                "workload": f"{args.config}: pig mesh [{mesh_note}; default = displaced icosphere level {level}], "
+                            f"{len(data.triangles)} triangles, {W}x{H}, {scene_spp(sub)} spp, {n_lights} lights, "
                             f"form {args.form} ({'bounded by Sphere(boundingObjects:)' if args.form == 'B' else 'top-level triangles'}), "
                             "list-order hit policy" + (", orbiting camera" if args.orbit else ""),
-                "mesh": "stand-in (no pig OBJ available offline)",
+                "mesh": mesh_note,
                 "tiles": "32x32 cyclic over ranks, own pixels gathered on rank 0" if world > 1 else "single GPU, whole frame",
             },
             "verified_against_single_gpu_frame": verified,
