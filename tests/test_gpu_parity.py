@@ -217,6 +217,23 @@ def test_high_poly_mesh_window(oracle_mod, rt):
     assert_parity(oracle_mod, rt, data, cam, scenes.make_params(480, 270, 0.5, window=(200, 110, 280, 160)))
 
 
+def test_config4_1_3m_triangles_full_frame_windows(oracle_mod, rt):
+    """Config 4 at full size (1,310,720 triangles, 1920x1080, 4 spp, brute force): the whole frame is
+    rendered on the GPU; a silhouette window and a centre window are checked against the oracle."""
+    data = scenes.mesh_scene(8, "B", 1, bounding_sphere=rt.bounding_sphere)
+    assert len(data.triangles) == 1310720
+    cam = scenes.make_camera(**scenes.MESH_CAMERA)
+    sc = rt.Scene(data)
+    full, fhit, cnt = sc.render(cam, scenes.make_params(1920, 1080, 0.5))
+    sc.close()
+    assert cnt["samples"] == 1919 * 1079 * 4 and cnt["rays_reflection"] == cnt["primary_hits"] > 0
+    for win in ((950, 535, 974, 547), (655, 310, 679, 322)):
+        x0, y0, x1, y1 = win
+        o_rgba, o_hit, _ = oracle_mod.render(data, cam, scenes.make_params(1920, 1080, 0.5, window=win), threads=16)
+        assert (o_hit[y0:y1, x0:x1] == fhit[y0:y1, x0:x1]).all()
+        assert int(np.abs(o_rgba[y0:y1, x0:x1].astype(int) - full[y0:y1, x0:x1].astype(int)).max()) <= 1
+
+
 def test_render_errors(rt):
     sc = rt.Scene(scenes.two_sphere_scene())
     cam = scenes.make_camera(**scenes.VC_CAMERA)
