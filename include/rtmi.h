@@ -103,6 +103,15 @@ typedef enum {
   RTMI_HIT_LIST_ORDER = 0 /* reference-exact: lowest list position that is hit */
 } rtmi_hit_policy;
 
+/* How the triangles of a group are searched for a primary ray.  Both give the same hits. */
+typedef enum {
+  RTMI_SEARCH_CONE_TREE = 0, /* default: per-frame cone hierarchy over a spatial order of the
+                                triangles; all hits of a ray are found, the lowest list position wins */
+  RTMI_SEARCH_LIST_SCAN = 1  /* every triangle a ray from the camera can face, in list order, until the
+                                ray's first hit: the reference's own loop (RayTracingFunctions.swift:86-93)
+                                behind an FP32 filter */
+} rtmi_search;
+
 /* Render parameters.  width/height are the globals imageWidth/imageHeight
  * (ViewController.swift:13-14); the reference renders pixels [0,W-1) x [0,H-1)
  * (RayTracingFunctions.swift:170, WorldCoordinateSequence.swift:69-87).
@@ -119,7 +128,7 @@ typedef struct {
   int32_t tile_size;      /* square tile edge in pixels; 0 = no tiling */
   int32_t tile_rank;      /* render tiles whose id % tile_world == tile_rank */
   int32_t tile_world;     /* <= 1 = every tile */
-  int32_t pad_;
+  int32_t search;         /* rtmi_search */
 } rtmi_params;
 
 /* Work and timing counters of one render call. */
@@ -127,7 +136,7 @@ typedef struct {
   int64_t samples;          /* primary rays generated                                    */
   int64_t rays_reflection;  /* RayTracingFunctions.swift:212                             */
   int64_t rays_shadow;      /* RayTracingFunctions.swift:236                             */
-  int64_t tri_tests;        /* (ray, triangle) pairs evaluated                           */
+  int64_t tri_tests;        /* (ray, triangle) pairs evaluated (culled or skipped pairs are not counted) */
   int64_t sphere_tests;     /* (ray, sphere|light) pairs evaluated                       */
   int64_t tri_exact_tests;  /* pairs that went through the FP64 reference-order test     */
   int64_t primary_hits;     /* samples that were shaded                                  */
@@ -135,7 +144,9 @@ typedef struct {
                                  counted like the reference counts them but not traced, since
                                  nothing they could hit can change the pixel
                                  (RayTracingFunctions.swift:245)                          */
-  int64_t reserved_[2];
+  int64_t node_tests;       /* cone tree only: (ray, inner node) pairs evaluated         */
+  int64_t tri_candidates;   /* cone tree only: pairs that passed the triangle cone and went
+                               on to the edge test                                       */
   double ms_total;          /* device time of the whole call (HIP events)                */
   double ms_tri_search;     /* device time of the triangle search launches only          */
   int64_t tri_search_launches;

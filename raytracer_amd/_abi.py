@@ -58,20 +58,23 @@ class Params(C.Structure):
                 ("ambient", D3), ("hit_policy", C.c_int32),
                 ("x0", C.c_int32), ("y0", C.c_int32), ("x1", C.c_int32), ("y1", C.c_int32),
                 ("tile_size", C.c_int32), ("tile_rank", C.c_int32), ("tile_world", C.c_int32),
-                ("pad_", C.c_int32)]
+                ("search", C.c_int32)]
 
 
 class Counters(C.Structure):
     _fields_ = [("samples", C.c_int64), ("rays_reflection", C.c_int64), ("rays_shadow", C.c_int64),
                 ("tri_tests", C.c_int64), ("sphere_tests", C.c_int64),
                 ("tri_exact_tests", C.c_int64), ("primary_hits", C.c_int64),
-                ("shadow_rays_elided", C.c_int64), ("reserved_", C.c_int64 * 2), ("ms_total", C.c_double), ("ms_tri_search", C.c_double),
+                ("shadow_rays_elided", C.c_int64), ("node_tests", C.c_int64), ("tri_candidates", C.c_int64), ("ms_total", C.c_double), ("ms_tri_search", C.c_double),
                 ("tri_search_launches", C.c_int64), ("tri_tests_primary_kernel", C.c_int64),
                 ("ms_primary_kernel", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved_"}
 
+
+RTMI_SEARCH_CONE_TREE = 0
+RTMI_SEARCH_LIST_SCAN = 1
 
 # every symbol include/rtmi.h declares
 EXPORTS = [

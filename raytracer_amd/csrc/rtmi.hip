@@ -26,6 +26,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/rtmi.h"
@@ -79,13 +80,19 @@ struct FrameConst {
 
 // Work counters are striped over NSLOT cache lines (one 64-byte line per slot) so that the
 // per-wave atomic adds of a launch do not serialise on one address; the host sums the slots.
-enum { C_REFL = 0, C_SHADOW, C_EXACT, C_HITS, C_TESTS_PRIMARY, C_TESTS_SECONDARY, C_SHADOW_ELIDED, C_NCOUNTERS = 8 };
+enum { C_REFL = 0, C_SHADOW, C_EXACT, C_HITS, C_TESTS_PRIMARY, C_TESTS_SECONDARY, C_SHADOW_ELIDED, C_NODE_TESTS, C_NCOUNTERS = 8 };
 constexpr int NSLOT = 64;
 
 struct DevCounters {
   unsigned long long slot[NSLOT][C_NCOUNTERS];
   int q_child, q_shade, q_top;  // queue fill levels
-  int pad;
+  int overflow;                 // a candidate list of the tree search did not fit
+  int pad[4];
+  unsigned long long cand_total;  // candidates of all tree search launches of the frame
+  // The tree search keeps NSLOT candidate lists (a wave appends to list `wave & 63`), each with its
+  // fill level on a cache line of its own: returning atomics on ONE address complete at roughly
+  // one per 30 ns, which a launch of 200,000 waves cannot afford.
+  int cand_n[NSLOT][16];
 };
 
 struct SceneDev {
@@ -335,6 +342,8 @@ __global__ void k_pack_write(const rtmi_triangle* __restrict__ tris, const int* 
   }
   packed_tri[pos] = ti;
 }
+
+#include "rtmi_tree.h"
 
 // General-origin filter data for the top-level triangle runs (rays that start on surfaces:
 // reflection and shadow rays, RayTracingFunctions.swift:212,236).  All FP32 values are relative
@@ -699,7 +708,81 @@ struct SearchArgs {
   const TriPlane* planes;
   double cam[3];
   int mode, obj_filter;
+  const int* group;  // list position -> triangle index (the tree search keeps positions)
+  int* best_pos;     // per sample: lowest list position hit so far (tree search)
+  int2* cand;        // (sample, triangle slot) candidates of the tree search
+  int cand_cap;
+  TreeDev tree;
 };
+
+// The R rays of a lane: queue entries base + r*64 + lane.  An entry that does not belong to this
+// launch (past the queue end, or a sample whose first sphere-like hit is another object) gets
+// sid = -1 and a NaN direction, which passes no FP32 test.
+template <int R>
+__device__ __forceinline__ void search_prologue(const SearchArgs* ap, int base, int nq, int lane, int (&sid)[R],
+                                                float (&dx)[R], float (&dy)[R], float (&dz)[R]) {
+  const float qnan = __builtin_nanf("");
+  const int* queue = ap->queue;
+  const int* hit_id = ap->hit_id;
+  const double* dirs = ap->dirs;
+  const int mode = ap->mode, obj_filter = ap->obj_filter;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    int q = base + r * 64 + lane;
+    bool valid = q < nq;
+    sid[r] = valid ? queue[q] : -1;
+    if (valid && mode == 0 && hit_id[sid[r]] != -2 - obj_filter) sid[r] = -1;
+    dx[r] = dy[r] = dz[r] = qnan;
+    if (sid[r] >= 0) {
+      const double* dp = dirs + (size_t)sid[r] * 3;
+      dx[r] = (float)dp[0]; dy[r] = (float)dp[1]; dz[r] = (float)dp[2];
+    }
+  }
+}
+
+// best[r]: triangle index of ray r's hit, or -1.  Must be reached by every thread of the workgroup.
+template <int R>
+__device__ __forceinline__ void search_epilogue(const SearchArgs* ap, int base, int nq, int lane, const int (&sid)[R],
+                                                const int (&best)[R]) {
+  if (ap->mode == 0) {
+    // hits go to the shade queue: one returning atomic per workgroup for all R rays
+    int* hit_id = ap->hit_id;
+    int* q_shade = ap->q_shade;
+    DevCounters* cnt = ap->cnt;
+    __shared__ int wtot[4];
+    __shared__ int gbase;
+    const int w = threadIdx.x >> 6;
+    unsigned long long masks[R];
+    int wave_total = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (sid[r] >= 0) hit_id[sid[r]] = best[r];
+      masks[r] = __ballot(sid[r] >= 0 && best[r] >= 0);
+      wave_total += __popcll(masks[r]);
+    }
+    if (lane == 0) wtot[w] = wave_total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int tot = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+      gbase = tot ? atomicAdd(&cnt->q_shade, tot) : 0;
+    }
+    __syncthreads();
+    int pos = gbase;
+    for (int q = 0; q < w; ++q) pos += wtot[q];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (sid[r] >= 0 && best[r] >= 0) q_shade[pos + __popcll(masks[r] & ((1ull << lane) - 1ull))] = sid[r];
+      pos += __popcll(masks[r]);
+    }
+  } else {
+    int* tri_hit = ap->tri_hit;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      int q = base + r * 64 + lane;
+      if (q < nq) tri_hit[q] = best[r];
+    }
+  }
+}
 
 template <int R>
 __global__ void __launch_bounds__(256)
@@ -716,26 +799,9 @@ k_search_primary(const SearchArgs* __restrict__ ap, const f2* __restrict__ cone)
   int sid[R], best[R], upto[R];
   float dx[R], dy[R], dz[R];
   const float qnan = __builtin_nanf("");
-  {
-    const int* queue = ap->queue;
-    const int* hit_id = ap->hit_id;
-    const double* dirs = ap->dirs;
-    const int mode = ap->mode, obj_filter = ap->obj_filter;
+  search_prologue<R>(ap, base, nq, lane, sid, dx, dy, dz);
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      int q = base + r * 64 + lane;
-      bool valid = q < nq;
-      sid[r] = valid ? queue[q] : -1;
-      if (valid && mode == 0 && hit_id[sid[r]] != -2 - obj_filter) sid[r] = -1;
-      best[r] = -1;
-      upto[r] = 0;
-      dx[r] = dy[r] = dz[r] = qnan;
-      if (sid[r] >= 0) {
-        const double* dp = dirs + (size_t)sid[r] * 3;
-        dx[r] = (float)dp[0]; dy[r] = (float)dp[1]; dz[r] = (float)dp[2];
-      }
-    }
-  }
+  for (int r = 0; r < R; ++r) { best[r] = -1; upto[r] = 0; }
 
   int done_batches = nbatch;
   if (nbatch > 0) {
@@ -857,43 +923,303 @@ k_search_primary(const SearchArgs* __restrict__ ap, const f2* __restrict__ cone)
   wave_count(cnt, C_TESTS_PRIMARY, tests);
   wave_count(cnt, C_EXACT, (unsigned long long)n_exact);
 
-  if (ap->mode == 0) {
-    // hits go to the shade queue: one returning atomic per workgroup for all R rays
-    int* hit_id = ap->hit_id;
-    int* q_shade = ap->q_shade;
-    __shared__ int wtot[4];
-    __shared__ int gbase;
-    const int w = threadIdx.x >> 6;
-    unsigned long long masks[R];
-    int wave_total = 0;
+  search_epilogue<R>(ap, base, nq, lane, sid, best);
+}
+
+// ---------------------------------------------------------------------------------------
+// the default search: cone tree (rtmi_tree.h) in three launches
+// ---------------------------------------------------------------------------------------
+//   k_search_tree    FP32 only: walks the tree once per wave and emits every (ray, triangle slot)
+//                    pair that passes the triangle's cone and edge tests -- the candidates
+//   k_search_exact   one lane per candidate: the FP64 reference-order test; a hit lowers the
+//                    ray's best list position (atomicMin)
+//   k_search_finish  one lane per ray: best list position -> triangle index, t, shade queue
+// Splitting the double-precision work off keeps the walk at a register count that allows eight
+// waves per SIMD (the walk is a chain of dependent scalar loads; occupancy hides their latency)
+// and runs the FP64 tests with all 64 lanes busy.
+constexpr int CAND_STAGE = 512;  // candidates a wave collects in LDS before it reserves global space
+
+// Evaluate one record of inner-node cones for the R rays of every lane; returns the mask of
+// children that some ray of the wave passes, or that are flagged "always descend".
+template <int R>
+__device__ __forceinline__ unsigned tree_eval(const f2* __restrict__ rp, const float (&dx)[R], const float (&dy)[R],
+                                              const float (&dz)[R]) {
+  f2 cur[12];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      if (sid[r] >= 0) hit_id[sid[r]] = best[r];
-      masks[r] = __ballot(sid[r] >= 0 && best[r] >= 0);
-      wave_total += __popcll(masks[r]);
-    }
-    if (lane == 0) wtot[w] = wave_total;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      int tot = wtot[0] + wtot[1] + wtot[2] + wtot[3];
-      gbase = tot ? atomicAdd(&cnt->q_shade, tot) : 0;
-    }
-    __syncthreads();
-    int pos = gbase;
-    for (int q = 0; q < w; ++q) pos += wtot[q];
+  for (int c = 0; c < 12; ++c) cur[c] = rp[c];
+  unsigned mask = reinterpret_cast<const unsigned*>(rp)[REC_ALWAYS];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      if (sid[r] >= 0 && best[r] >= 0) q_shade[pos + __popcll(masks[r] & ((1ull << lane) - 1ull))] = sid[r];
-      pos += __popcll(masks[r]);
+  for (int pr = 0; pr < 4; ++pr) {
+    f2 q[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { f2 X = {dx[r], dx[r]}; q[r] = cur[pr * 3 + 0] * X; }
+#pragma unroll
+    for (int r = 0; r < R; ++r) { f2 Y = {dy[r], dy[r]}; q[r] = __builtin_elementwise_fma(cur[pr * 3 + 1], Y, q[r]); }
+#pragma unroll
+    for (int r = 0; r < R; ++r) { f2 Z = {dz[r], dz[r]}; q[r] = __builtin_elementwise_fma(cur[pr * 3 + 2], Z, q[r]); }
+    float ma = q[0].x, mb = q[0].y;  // fmaxf drops the NaN of absent rays
+#pragma unroll
+    for (int r = 1; r < R; ++r) { ma = __builtin_fmaxf(ma, q[r].x); mb = __builtin_fmaxf(mb, q[r].y); }
+    if (__any(ma >= 1.0f)) mask |= 1u << (2 * pr);
+    if (__any(mb >= 1.0f)) mask |= 2u << (2 * pr);
+  }
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)mask);
+}
+
+// Hand the wave's staged candidates to its global list: one returning atomic per flush.
+__device__ __forceinline__ void cand_flush(const SearchArgs* ap, const int2* stage, int fill, int lane, int list) {
+  if (fill == 0) return;
+  DevCounters* cnt = ap->cnt;
+  const int list_cap = ap->cand_cap / NSLOT;
+  int base = 0;
+  if (lane == 0) base = atomicAdd(&cnt->cand_n[list][0], fill);
+  base = __builtin_amdgcn_readfirstlane(base);
+  if (base + fill > list_cap || base < 0) {
+    if (lane == 0) cnt->overflow = 1;  // the caller renders this frame again with the list scan
+    return;
+  }
+  int2* cand = ap->cand + (size_t)list * list_cap + base;
+  for (int i = lane; i < fill; i += 64) cand[i] = stage[i];
+}
+
+// Each wave walks the tree depth first for its R*64 rays.  The walk is wave-uniform: `lvl`, the
+// record index `ri` and `masks` (one byte of children still to visit per level) live in scalar
+// registers.  Record (l, r) holds the cones of nodes 8r..8r+7 of level l; the children of node
+// (l, j) are record (l-1, j); level-0 nodes are triangle slots, and a level-0 record is not
+// pushed but evaluated per lane: every (ray, slot) pair that passes becomes a candidate.
+template <int R>
+__global__ void __launch_bounds__(256)
+k_search_tree(const SearchArgs* __restrict__ ap, const f2* __restrict__ rec, const float* __restrict__ edge_all) {
+  __shared__ int2 stage_all[4][CAND_STAGE];
+  const int nq = *ap->nq_ptr;
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int base = wave * 64 * R;
+  if (base >= nq) return;  // no workgroup-wide synchronisation below: waves leave on their own
+  int2* stage = stage_all[threadIdx.x >> 6];
+
+  int sid[R];
+  float dx[R], dy[R], dz[R];
+  search_prologue<R>(ap, base, nq, lane, sid, dx, dy, dz);
+  {
+    int* best_pos = ap->best_pos;  // this launch decides these rays: no hit so far
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (sid[r] >= 0) best_pos[sid[r]] = 0x7fffffff;
+  }
+  unsigned n_leaf_rec = 0, n_node_rec = 0;
+  int fill = 0;
+
+  const int ltop = ap->tree.ltop, n_root = ap->tree.n_root;
+  // first record of each level, in scalar registers; the select chain is scalar code
+  const int o0 = ap->tree.rec_off[0], o1 = ap->tree.rec_off[1], o2 = ap->tree.rec_off[2], o3 = ap->tree.rec_off[3],
+            o4 = ap->tree.rec_off[4], o5 = ap->tree.rec_off[5], o6 = ap->tree.rec_off[6], o7 = ap->tree.rec_off[7];
+  static_assert(TREE_MAX_LEVELS == 8, "level_off lists eight levels");
+  auto level_off = [&](int lvl) {
+    return lvl == 1 ? o1 : lvl == 2 ? o2 : lvl == 3 ? o3 : lvl == 4 ? o4 : lvl == 5 ? o5 : lvl == 6 ? o6 : o7;
+  };
+  // Level-0 record `ri`: the triangle cones of slots 8*ri..8*ri+7 against every ray of the lane,
+  // then, triangle by triangle, the edge test for the rays that passed; what remains is a candidate.
+  typedef typename std::conditional<(R > 4), unsigned long long, unsigned int>::type bits_t;
+  auto leaf = [&](int ri) {
+    ++n_leaf_rec;
+    const f2* rp = rec + (size_t)(o0 + ri) * (REC_DWORDS / 2);
+    bits_t bits = 0;  // bit j*R + r: ray r of this lane passes the cone of the record's triangle j
+    {
+      f2 cur[12];
+#pragma unroll
+      for (int c = 0; c < 12; ++c) cur[c] = rp[c];
+#pragma unroll
+      for (int pr = 0; pr < 4; ++pr) {
+        f2 q[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { f2 X = {dx[r], dx[r]}; q[r] = cur[pr * 3 + 0] * X; }
+#pragma unroll
+        for (int r = 0; r < R; ++r) { f2 Y = {dy[r], dy[r]}; q[r] = __builtin_elementwise_fma(cur[pr * 3 + 1], Y, q[r]); }
+#pragma unroll
+        for (int r = 0; r < R; ++r) { f2 Z = {dz[r], dz[r]}; q[r] = __builtin_elementwise_fma(cur[pr * 3 + 2], Z, q[r]); }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          // !(q < 1) also lets a NaN cone (wide triangle) through; absent rays have NaN directions
+          if (!(q[r].x < 1.0f) && sid[r] >= 0) bits |= (bits_t)1 << ((pr * 2) * R + r);
+          if (!(q[r].y < 1.0f) && sid[r] >= 0) bits |= (bits_t)1 << ((pr * 2 + 1) * R + r);
+        }
+      }
     }
+    if (!__any(bits != 0)) return;
+    const float* edge = edge_all + (size_t)ri * (8 * EDGE_FLOATS);
+#pragma nounroll
+    for (int j = 0; j < 8; ++j) {
+      const unsigned mine = (unsigned)(bits >> (j * R)) & ((1u << R) - 1u);
+      if (!__any(mine != 0)) continue;
+      const float* m = edge + j * EDGE_FLOATS;
+      const float m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3], m4 = m[4], m5 = m[5], m6 = m[6], m7 = m[7], m8 = m[8];
+      const int g = ri * 8 + j;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float s0 = __builtin_fmaf(m2, dz[r], __builtin_fmaf(m1, dy[r], m0 * dx[r]));
+        float s1 = __builtin_fmaf(m5, dz[r], __builtin_fmaf(m4, dy[r], m3 * dx[r]));
+        float s2 = __builtin_fmaf(m8, dz[r], __builtin_fmaf(m7, dy[r], m6 * dx[r]));
+        float e = __builtin_fmaxf(__builtin_fmaxf(s0, s1), s2);
+        const bool pass = ((mine >> r) & 1u) && e <= 1.0f;
+        const unsigned long long bm = __ballot(pass);
+        if (bm == 0) continue;
+        const int n = __popcll(bm);
+        if (fill + n > CAND_STAGE) {
+          cand_flush(ap, stage, fill, lane, wave & (NSLOT - 1));
+          fill = 0;
+          __builtin_amdgcn_wave_barrier();
+        }
+        if (pass) stage[fill + __popcll(bm & ((1ull << lane) - 1ull))] = make_int2(sid[r], g);
+        fill += n;
+      }
+    }
+  };
+
+  if (ltop == 0) {
+    for (int t = 0; t < n_root; ++t) leaf(t);
   } else {
-    int* tri_hit = ap->tri_hit;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      int q = base + r * 64 + lane;
-      if (q < nq) tri_hit[q] = best[r];
+    for (int t = 0; t < n_root; ++t) {
+      int lvl = ltop, ri = t;
+      unsigned long long masks;
+      {
+        unsigned m = tree_eval<R>(rec + (size_t)(level_off(lvl) + ri) * (REC_DWORDS / 2), dx, dy, dz);
+        masks = (unsigned long long)m << (8 * lvl);
+        ++n_node_rec;
+      }
+      for (;;) {
+        const unsigned cur = (unsigned)(masks >> (8 * lvl)) & 0xffu;
+        if (cur == 0) {
+          if (lvl == ltop) break;
+          ++lvl;
+          ri >>= 3;
+          continue;
+        }
+        const int c = __builtin_ctz(cur);
+        masks &= ~(1ull << (8 * lvl + c));
+        const int child = ri * 8 + c;
+        if (lvl == 1) {
+          leaf(child);
+        } else {
+          --lvl;
+          ri = child;
+          unsigned m = tree_eval<R>(rec + (size_t)(level_off(lvl) + ri) * (REC_DWORDS / 2), dx, dy, dz);
+          masks |= (unsigned long long)m << (8 * lvl);
+          ++n_node_rec;
+        }
+      }
     }
   }
+  __builtin_amdgcn_wave_barrier();
+  cand_flush(ap, stage, fill, lane, wave & (NSLOT - 1));
+
+  // work counters: (ray, triangle) cone tests at leaf level, (ray, node) tests above it
+  int active = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) active += __popcll(__ballot(sid[r] >= 0));
+  DevCounters* cnt = ap->cnt;
+  wave_count(cnt, C_TESTS_PRIMARY, lane == 0 ? 8ull * n_leaf_rec * (unsigned long long)active : 0ull);
+  wave_count(cnt, C_NODE_TESTS, lane == 0 ? 8ull * n_node_rec * (unsigned long long)active : 0ull);
+}
+
+// One lane per candidate: the reference's own arithmetic in FP64; a hit competes for the ray's
+// lowest list position.  Workgroup w serves candidate list w & 63 together with the other
+// workgroups of that residue (the grid is a multiple of 64 workgroups).
+__global__ void __launch_bounds__(256)
+k_search_exact(const SearchArgs* __restrict__ ap) {
+  const DevCounters* cnt = ap->cnt;
+  unsigned int n_exact = 0;
+  if (!cnt->overflow) {  // after an overflow the lists are incomplete and the frame is rendered again
+    const int list = blockIdx.x & (NSLOT - 1), part = blockIdx.x / NSLOT, parts = gridDim.x / NSLOT;
+    const int list_cap = ap->cand_cap / NSLOT;
+    const int n = cnt->cand_n[list][0];
+    const int2* cand = ap->cand + (size_t)list * list_cap;
+    const double* dirs = ap->dirs;
+    const d3 o = rtx::ld3(ap->cam);
+    for (int i = part * blockDim.x + threadIdx.x; i < n; i += parts * blockDim.x) {
+      const int2 c = cand[i];
+      const int s = c.x, g = c.y;
+      const double* dp = dirs + (size_t)s * 3;
+      const int ti = ap->tree.slot_tri[g];
+      if (ti < 0) continue;  // padding slot (its zero cone passes nothing; belt and braces)
+      const rtmi_triangle& tr = ap->tris[ti];
+      d3 P;
+      double tv;
+      n_exact += 1;
+      if (rtx::tri_hit(rtx::ld3(tr.v[0]), rtx::ld3(tr.v[1]), rtx::ld3(tr.v[2]), ap->planes[ti], o,
+                       rtx::mk(dp[0], dp[1], dp[2]), &tv, &P))
+        atomicMin(&ap->best_pos[s], ap->tree.slot_pos[g]);
+    }
+  }
+  wave_count(ap->cnt, C_EXACT, (unsigned long long)n_exact);
+}
+
+// One lane per ray of the launch's queue: the lowest list position that was hit -> triangle
+// index, t (the same FP64 evaluation once more: it is deterministic) and the shade queue.
+// Persistent workgroups: each walks the queue in 256-ray steps and collects its hits in LDS, so
+// that the shade queue's fill level sees one returning atomic per FINISH_STAGE hits, not one per step.
+constexpr int FINISH_STAGE = 8192;
+__global__ void __launch_bounds__(256)
+k_search_finish(const SearchArgs* __restrict__ ap) {
+  __shared__ int stage[FINISH_STAGE];
+  __shared__ int wtot[2][4];  // per-wave hit counts of the current step, double-buffered by step parity
+  __shared__ int gbase;
+  const int nq = *ap->nq_ptr;
+  DevCounters* cnt = ap->cnt;
+  if (blockIdx.x == 0 && threadIdx.x < NSLOT) {  // k_search_exact is done with the candidate lists
+    atomicAdd(&cnt->cand_total, (unsigned long long)(unsigned int)cnt->cand_n[threadIdx.x][0]);
+    cnt->cand_n[threadIdx.x][0] = 0;
+  }
+  const int mode = ap->mode;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  // `fill` is kept in a register by every thread and updated identically by all of them, so the
+  // decision to flush is the same in every wave (a shared counter would be read by a slow wave
+  // after a fast wave had already added this step's hits to it).
+  int fill = 0, parity = 0;
+  auto flush = [&]() {  // reached by all threads of the workgroup, or by none
+    if (threadIdx.x == 0) gbase = fill ? atomicAdd(&cnt->q_shade, fill) : 0;
+    __syncthreads();  // gbase is visible; every wave has finished writing its staged hits
+    int* q_shade = ap->q_shade + gbase;
+    for (int i = threadIdx.x; i < fill; i += blockDim.x) q_shade[i] = stage[i];
+    __syncthreads();  // the stage may be overwritten from here on
+    fill = 0;
+  };
+  for (int q0 = blockIdx.x * blockDim.x; q0 < nq; q0 += gridDim.x * blockDim.x) {
+    const int q = q0 + threadIdx.x;
+    const bool valid = q < nq;
+    int s = valid ? ap->queue[q] : -1;
+    if (valid && mode == 0 && ap->hit_id[s] != -2 - ap->obj_filter) s = -1;
+    int ti = -1;
+    if (s >= 0) {
+      const int pos = ap->best_pos[s];
+      if (pos != 0x7fffffff) {
+        ti = ap->group[pos];
+        const rtmi_triangle& tr = ap->tris[ti];
+        const double* dp = ap->dirs + (size_t)s * 3;
+        d3 P;
+        double tv = 0.0;
+        rtx::tri_hit(rtx::ld3(tr.v[0]), rtx::ld3(tr.v[1]), rtx::ld3(tr.v[2]), ap->planes[ti], rtx::ld3(ap->cam),
+                     rtx::mk(dp[0], dp[1], dp[2]), &tv, &P);
+        ap->tval[s] = tv;  // the hit point is origin + t*direction; shading rebuilds it
+      }
+    }
+    if (mode == 0) {
+      if (s >= 0) ap->hit_id[s] = ti;
+      if (fill + (int)blockDim.x > FINISH_STAGE) flush();
+      const bool hit = s >= 0 && ti >= 0;
+      const unsigned long long m = __ballot(hit);
+      if (lane == 0) wtot[parity][w] = __popcll(m);
+      __syncthreads();
+      int pos = fill;
+      for (int k = 0; k < w; ++k) pos += wtot[parity][k];
+      if (hit) stage[pos + __popcll(m & ((1ull << lane) - 1ull))] = s;
+      fill += wtot[parity][0] + wtot[parity][1] + wtot[parity][2] + wtot[parity][3];
+      parity ^= 1;  // the next step writes the other half: a slow wave may still be reading this one
+    } else if (valid) {
+      ap->tri_hit[q] = ti;
+    }
+  }
+  if (mode == 0) flush();
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1135,6 +1461,14 @@ struct TriGroup {
   int* d_packed_tri = nullptr;
   int* d_npacked = nullptr;     // triangles kept by the last pack
   size_t cone_bytes = 0;
+  // cone tree (rtmi_tree.h): spatial slot order fixed at scene creation, cones rebuilt per frame
+  TreeDev tree{};
+  int* d_slot_tri = nullptr;
+  int* d_slot_pos = nullptr;
+  float* d_rec = nullptr;
+  float* d_tedge = nullptr;
+  NodeCone* d_nodes = nullptr;
+  unsigned int* d_ticket = nullptr;
 };
 
 struct rtmi_scene {
@@ -1165,6 +1499,8 @@ struct rtmi_scene {
   double* d_rgb = nullptr;
   double* d_dirs = nullptr;
   double* d_tval = nullptr;
+  int* d_best_pos = nullptr;   // tree search: per sample, lowest list position hit
+  int2* d_cand = nullptr;      // tree search: candidate pairs, cap_samples entries
   FrameConst* d_fc = nullptr;
   FrameConst h_fc{};
   SceneDev* d_scdev = nullptr;       // device copy of `dev` for kernels that take it by pointer
@@ -1178,6 +1514,7 @@ struct rtmi_scene {
   std::array<int, 9> blocks_key{};     // frame geometry + tile selection it was built for
   bool blocks_valid = false;
   DevCounters* d_cnt = nullptr;
+  int exact_grid = 2048;  // workgroups of the grid-stride k_search_exact: eight per compute unit
   // one frame may be in flight between rtmi_render_begin and rtmi_render_end
   bool pending = false;
   DevCounters* h_cnt = nullptr;  // pinned host copy of the device counters
@@ -1185,6 +1522,10 @@ struct rtmi_scene {
   size_t ev_used = 0;
   long long pend_launches = 0;
   int64_t pend_live_samples = 0;
+  rtmi_camera pend_cam{};
+  rtmi_params pend_params{};
+  void* pend_rgba = nullptr;
+  void* pend_hit = nullptr;
   std::mutex mu;
 };
 
@@ -1215,7 +1556,7 @@ static int32_t validate_scene(const rtmi_scene_desc* s) {
   return RTMI_OK;
 }
 
-static int32_t alloc_group(TriGroup& g, const std::vector<int>& idx) {
+static int32_t alloc_group(TriGroup& g, const std::vector<int>& idx, const rtmi_triangle* tris) {
   // An empty group (a bounding sphere without children) still gets its buffers: the search
   // kernel then runs with npacked == 0 and resolves every queued sample as a miss.
   g.n = (int)idx.size();
@@ -1232,6 +1573,28 @@ static int32_t alloc_group(TriGroup& g, const std::vector<int>& idx) {
   HIP_TRY(hipMalloc(&g.d_packed_tri, sizeof(int) * n1));
   HIP_TRY(hipMalloc(&g.d_npacked, sizeof(int)));
   HIP_TRY(hipMemset(g.d_npacked, 0, sizeof(int)));
+
+  TreeHost th;
+  tree_build_host(tris, idx, &th);
+  g.tree = th.dev;
+  const size_t ns = th.slot_tri.size();
+  HIP_TRY(hipMalloc(&g.d_slot_tri, sizeof(int) * ns));
+  HIP_TRY(hipMemcpy(g.d_slot_tri, th.slot_tri.data(), sizeof(int) * ns, hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&g.d_slot_pos, sizeof(int) * ns));
+  HIP_TRY(hipMemcpy(g.d_slot_pos, th.slot_pos.data(), sizeof(int) * ns, hipMemcpyHostToDevice));
+  // entries of nodes that do not exist (the tail of a level's last record) stay zero for ever
+  HIP_TRY(hipMalloc(&g.d_rec, sizeof(float) * REC_DWORDS * th.n_records));
+  HIP_TRY(hipMemset(g.d_rec, 0, sizeof(float) * REC_DWORDS * th.n_records));
+  HIP_TRY(hipMalloc(&g.d_tedge, sizeof(float) * EDGE_FLOATS * ns));
+  HIP_TRY(hipMalloc(&g.d_nodes, sizeof(NodeCone) * th.n_node_buf));
+  HIP_TRY(hipMalloc(&g.d_ticket, sizeof(unsigned int)));
+  HIP_TRY(hipMemset(g.d_ticket, 0, sizeof(unsigned int)));
+  g.tree.slot_tri = g.d_slot_tri;
+  g.tree.slot_pos = g.d_slot_pos;
+  g.tree.rec = g.d_rec;
+  g.tree.edge = g.d_tedge;
+  g.tree.nodes = g.d_nodes;
+  g.tree.ticket = g.d_ticket;
   return RTMI_OK;
 }
 
@@ -1295,13 +1658,15 @@ extern "C" void rtmi_scene_destroy(rtmi_scene* sc) {
   for (auto& g : sc->groups) {
     (void)hipFree(g.d_group); (void)hipFree(g.d_keep); (void)hipFree(g.d_block_counts);
     (void)hipFree(g.d_cone); (void)hipFree(g.d_edge); (void)hipFree(g.d_packed_tri); (void)hipFree(g.d_npacked);
+    (void)hipFree(g.d_slot_tri); (void)hipFree(g.d_slot_pos); (void)hipFree(g.d_rec); (void)hipFree(g.d_tedge);
+    (void)hipFree(g.d_nodes); (void)hipFree(g.d_ticket);
   }
   (void)hipFree(sc->d_objects); (void)hipFree(sc->d_lights); (void)hipFree(sc->d_materials);
   (void)hipFree(sc->d_tris); (void)hipFree(sc->d_planes); (void)hipFree(sc->d_tri_owner);
   (void)hipFree(sc->d_gsph); (void)hipFree(sc->d_gst2); (void)hipFree(sc->d_run_start);
   (void)hipFree(sc->d_hit_id); (void)hipFree(sc->d_tri_hit); (void)hipFree(sc->d_q_child);
   (void)hipFree(sc->d_q_shade); (void)hipFree(sc->d_q_top); (void)hipFree(sc->d_rgb);
-  (void)hipFree(sc->d_dirs); (void)hipFree(sc->d_tval); (void)hipFree(sc->d_fc); (void)hipFree(sc->d_tabs); (void)hipFree(sc->d_sargs); (void)hipFree(sc->d_scdev);
+  (void)hipFree(sc->d_dirs); (void)hipFree(sc->d_tval); (void)hipFree(sc->d_best_pos); (void)hipFree(sc->d_cand); (void)hipFree(sc->d_fc); (void)hipFree(sc->d_tabs); (void)hipFree(sc->d_sargs); (void)hipFree(sc->d_scdev);
   (void)hipFree(sc->d_blocks); (void)hipFree(sc->d_cnt);
   if (sc->h_cnt) (void)hipHostFree(sc->h_cnt);
   for (auto& pr : sc->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -1327,6 +1692,7 @@ static int32_t scene_create_impl(const rtmi_scene_desc* desc, int32_t device, rt
     return RTMI_ERR_NO_DEVICE;
   }
   sc->device = device;
+  sc->exact_grid = ((std::max(1, prop.multiProcessorCount) * 8 + NSLOT - 1) / NSLOT) * NSLOT;  // a multiple of NSLOT
   HIP_TRY(hipSetDevice(device));
   HIP_TRY(hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreate(&sc->ev_a));
@@ -1386,9 +1752,9 @@ static int32_t scene_create_impl(const rtmi_scene_desc* desc, int32_t device, rt
     std::sort(sorted.begin(), sorted.end());
     if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end()) return RTMI_ERR_UNSUPPORTED;
   }
-  if ((rc = alloc_group(sc->groups[0], top))) return rc;
+  if ((rc = alloc_group(sc->groups[0], top, desc->triangles))) return rc;
   for (size_t g = 1; g < sc->groups.size(); ++g)
-    if ((rc = alloc_group(sc->groups[g], child_lists[g - 1]))) return rc;
+    if ((rc = alloc_group(sc->groups[g], child_lists[g - 1], desc->triangles))) return rc;
   if ((rc = upload((void**)&sc->d_tri_owner, owner.data(), sizeof(int) * owner.size()))) return rc;
 
   if (desc->n_triangles > 0) {
@@ -1480,9 +1846,10 @@ static int32_t ensure_buffers(rtmi_scene* sc, size_t samples, size_t blocks) {
   if (samples > sc->cap_samples) {
     (void)hipFree(sc->d_hit_id); (void)hipFree(sc->d_tri_hit); (void)hipFree(sc->d_q_child);
     (void)hipFree(sc->d_q_shade); (void)hipFree(sc->d_q_top); (void)hipFree(sc->d_rgb);
-    (void)hipFree(sc->d_dirs); (void)hipFree(sc->d_tval);
-    sc->d_hit_id = sc->d_tri_hit = sc->d_q_child = sc->d_q_shade = sc->d_q_top = nullptr;
+    (void)hipFree(sc->d_dirs); (void)hipFree(sc->d_tval); (void)hipFree(sc->d_best_pos); (void)hipFree(sc->d_cand);
+    sc->d_hit_id = sc->d_tri_hit = sc->d_q_child = sc->d_q_shade = sc->d_q_top = sc->d_best_pos = nullptr;
     sc->d_rgb = sc->d_dirs = sc->d_tval = nullptr;
+    sc->d_cand = nullptr;
     sc->cap_samples = 0;
     HIP_TRY(hipMalloc(&sc->d_hit_id, sizeof(int) * samples));
     HIP_TRY(hipMalloc(&sc->d_tri_hit, sizeof(int) * samples));
@@ -1492,6 +1859,8 @@ static int32_t ensure_buffers(rtmi_scene* sc, size_t samples, size_t blocks) {
     HIP_TRY(hipMalloc(&sc->d_rgb, sizeof(double) * 3 * samples));
     HIP_TRY(hipMalloc(&sc->d_dirs, sizeof(double) * 3 * samples));
     HIP_TRY(hipMalloc(&sc->d_tval, sizeof(double) * samples));
+    HIP_TRY(hipMalloc(&sc->d_best_pos, sizeof(int) * samples));
+    HIP_TRY(hipMalloc(&sc->d_cand, sizeof(int2) * samples));
     sc->cap_samples = samples;
   }
   if (blocks > sc->cap_blocks) {
@@ -1505,7 +1874,16 @@ static int32_t ensure_buffers(rtmi_scene* sc, size_t samples, size_t blocks) {
   return RTMI_OK;
 }
 
-// Run pack for one group against the frame's camera.
+// Per-frame cone tree of one group for the frame's camera position.
+static int32_t pack_group_tree(rtmi_scene* sc, TriGroup& g, d3 cam) {
+  if (g.n == 0) return RTMI_OK;  // the records were zeroed at creation: nothing passes
+  int nblocks = (g.tree.n_slots + TREE_BLOCK - 1) / TREE_BLOCK;
+  hipLaunchKernelGGL(k_pack_tree, dim3(nblocks), dim3(TREE_BLOCK), 0, sc->stream, sc->d_tris, sc->d_planes, g.tree, cam);
+  HIP_TRY(hipGetLastError());
+  return RTMI_OK;
+}
+
+// Run the list-scan pack for one group against the frame's camera.
 static int32_t pack_group(rtmi_scene* sc, TriGroup& g, d3 cam) {
   if (g.n == 0) return RTMI_OK;
   int nblocks = (g.n + 255) / 256;
@@ -1530,12 +1908,15 @@ static int search_rays_per_lane() {
 }
 constexpr size_t MAX_BATCH_SAMPLES = 1u << 28;  // 256 Mi samples per batch (68 B of work buffers per sample)
 
-// Enqueue a whole frame on the scene's stream; nothing here waits for the device.
-static int32_t render_begin_impl(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_params* p, void* rgba_dev,
-                                 void* hit_dev) {
+// Enqueue a whole frame on the scene's stream; nothing here waits for the device.  The caller
+// holds sc->mu.
+static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_params* p, void* rgba_dev,
+                              void* hit_dev) {
   if (!sc || !cam || !p || !rgba_dev) return RTMI_ERR_INVALID_ARGUMENT;
   if (p->width < 2 || p->height < 2) return RTMI_ERR_INVALID_ARGUMENT;
   if (p->hit_policy != RTMI_HIT_LIST_ORDER) return RTMI_ERR_UNSUPPORTED;
+  if (p->search != RTMI_SEARCH_CONE_TREE && p->search != RTMI_SEARCH_LIST_SCAN) return RTMI_ERR_INVALID_ARGUMENT;
+  const bool use_tree = p->search == RTMI_SEARCH_CONE_TREE;
   int spp = rtmi_samples_per_pixel(p->pixel_subdivision);
   if (spp < 0) return spp;
   int n1 = 1;
@@ -1547,7 +1928,6 @@ static int32_t render_begin_impl(rtmi_scene* sc, const rtmi_camera* cam, const r
     return RTMI_ERR_INVALID_ARGUMENT;
   if (p->tile_world > 1 && p->tile_size <= 0) return RTMI_ERR_INVALID_ARGUMENT;
 
-  std::lock_guard<std::mutex> lock(sc->mu);
   if (sc->pending) {
     g_last_error = "a frame is already in flight on this scene; call rtmi_render_end first";
     return RTMI_ERR_INVALID_ARGUMENT;
@@ -1653,7 +2033,7 @@ static int32_t render_begin_impl(rtmi_scene* sc, const rtmi_camera* cam, const r
   }
   d3 camera = rtx::ld3(cam->pos);
   for (auto& g : sc->groups)
-    if ((rc = pack_group(sc, g, camera))) return rc;
+    if ((rc = use_tree ? pack_group_tree(sc, g, camera) : pack_group(sc, g, camera))) return rc;
 
   // argument blocks of the search launches (one per triangle group), uploaded once per frame
   for (size_t gi = 0; gi < sc->groups.size(); ++gi) {
@@ -1675,6 +2055,11 @@ static int32_t render_begin_impl(rtmi_scene* sc, const rtmi_camera* cam, const r
     a.cam[0] = fc.cam[0]; a.cam[1] = fc.cam[1]; a.cam[2] = fc.cam[2];
     a.mode = gi == 0 ? 1 : 0;
     a.obj_filter = g.object;
+    a.group = g.d_group;
+    a.best_pos = sc->d_best_pos;
+    a.cand = sc->d_cand;
+    a.cand_cap = (int)std::min<size_t>(sc->cap_samples, 0x7fffffff);
+    a.tree = g.tree;
   }
   HIP_TRY(hipMemcpyAsync(sc->d_sargs, sc->h_sargs.data(), sizeof(SearchArgs) * sc->groups.size(), hipMemcpyHostToDevice, st));
 
@@ -1706,27 +2091,34 @@ static int32_t render_begin_impl(rtmi_scene* sc, const rtmi_camera* cam, const r
                        sc->d_q_shade, sc->d_q_top, sc->d_cnt);
     const int SR = search_rays_per_lane();
     const int search_grid = (nsamples + 256 * SR - 1) / (256 * SR);
-    auto search_kernel = SR == 8 ? k_search_primary<8> : (SR == 2 ? k_search_primary<2> : k_search_primary<4>);
-    if (sc->groups[0].n > 0) {
-      TriGroup& g = sc->groups[0];
+    auto scan_kernel = SR == 8 ? k_search_primary<8> : (SR == 2 ? k_search_primary<2> : k_search_primary<4>);
+    auto tree_kernel = SR == 8 ? k_search_tree<8> : (SR == 2 ? k_search_tree<2> : k_search_tree<4>);
+    // the triangle search of one group for the rays queued for it
+    auto search_group = [&](size_t gi) -> int32_t {
+      TriGroup& g = sc->groups[gi];
       hipEvent_t e0, e1;
-      if ((rc = next_events(&e0, &e1))) return rc;
+      int32_t rc2 = next_events(&e0, &e1);
+      if (rc2) return rc2;
       HIP_TRY(hipEventRecord(e0, st));
-      hipLaunchKernelGGL(search_kernel, dim3(search_grid), dim3(256), 0, st, sc->d_sargs + 0, (const f2*)g.d_cone);
+      if (use_tree) {
+        hipLaunchKernelGGL(tree_kernel, dim3(search_grid), dim3(256), 0, st, sc->d_sargs + gi, (const f2*)g.d_rec,
+                           (const float*)g.d_tedge);
+        hipLaunchKernelGGL(k_search_exact, dim3(sc->exact_grid), dim3(256), 0, st, sc->d_sargs + gi);
+        hipLaunchKernelGGL(k_search_finish, dim3(std::min(grid, sc->exact_grid)), dim3(256), 0, st, sc->d_sargs + gi);
+      } else {
+        hipLaunchKernelGGL(scan_kernel, dim3(search_grid), dim3(256), 0, st, sc->d_sargs + gi, (const f2*)g.d_cone);
+      }
       HIP_TRY(hipEventRecord(e1, st));
       ++launches;
+      return RTMI_OK;
+    };
+    if (sc->groups[0].n > 0) {
+      if ((rc = search_group(0))) return rc;
       hipLaunchKernelGGL(k_resolve_top, dim3(grid), dim3(256), 0, st, sc->dev, sc->d_q_top, &sc->d_cnt->q_top, sc->d_tri_hit,
                          sc->d_tri_owner, sc->d_hit_id, sc->d_q_child, sc->d_q_shade, sc->d_cnt);
     }
-    for (size_t gi = 1; gi < sc->groups.size(); ++gi) {
-      TriGroup& g = sc->groups[gi];
-      hipEvent_t e0, e1;
-      if ((rc = next_events(&e0, &e1))) return rc;
-      HIP_TRY(hipEventRecord(e0, st));
-      hipLaunchKernelGGL(search_kernel, dim3(search_grid), dim3(256), 0, st, sc->d_sargs + gi, (const f2*)g.d_cone);
-      HIP_TRY(hipEventRecord(e1, st));
-      ++launches;
-    }
+    for (size_t gi = 1; gi < sc->groups.size(); ++gi)
+      if ((rc = search_group(gi))) return rc;
     hipLaunchKernelGGL(sc->groups[0].n > 0 ? k_shade<true> : k_shade<false>, dim3(grid), dim3(256), 0, st, shc, sc->dev, sc->d_dirs, sc->d_tval, sc->d_q_shade, &sc->d_cnt->q_shade,
                        sc->d_hit_id, sc->d_rgb, sc->d_cnt);
     int npix = (int)(nb * BLK_PIX);
@@ -1738,8 +2130,19 @@ static int32_t render_begin_impl(rtmi_scene* sc, const rtmi_camera* cam, const r
   HIP_TRY(hipMemcpyAsync(sc->h_cnt, sc->d_cnt, sizeof(DevCounters), hipMemcpyDeviceToHost, st));
   sc->pend_launches = launches;
   sc->pend_live_samples = live_samples;
+  sc->pend_cam = *cam;
+  sc->pend_params = *p;
+  sc->pend_rgba = rgba_dev;
+  sc->pend_hit = hit_dev;
   sc->pending = true;
   return RTMI_OK;
+}
+
+static int32_t render_begin_impl(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_params* p, void* rgba_dev,
+                                 void* hit_dev) {
+  if (!sc) return RTMI_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lock(sc->mu);
+  return render_enqueue(sc, cam, p, rgba_dev, hit_dev);
 }
 
 // Wait for the frame enqueued by render_begin_impl and report its counters.
@@ -1753,6 +2156,19 @@ static int32_t render_end_impl(rtmi_scene* sc, rtmi_counters* counters) {
   sc->pending = false;
   HIP_TRY(hipSetDevice(sc->device));
   HIP_TRY(hipStreamSynchronize(sc->stream));
+  if (sc->h_cnt->overflow && sc->pend_params.search == RTMI_SEARCH_CONE_TREE) {
+    // More candidate pairs than the list holds (rays that pass very many triangle cones, e.g. deep
+    // stacks of overlapping triangles): the frame is rendered again with the list scan, which
+    // needs no such list and gives the same image.
+    rtmi_params p2 = sc->pend_params;
+    p2.search = RTMI_SEARCH_LIST_SCAN;
+    const rtmi_camera cam2 = sc->pend_cam;
+    int32_t rc = render_enqueue(sc, &cam2, &p2, sc->pend_rgba, sc->pend_hit);
+    if (rc != RTMI_OK) return rc;
+    sc->pending = false;
+    HIP_TRY(hipStreamSynchronize(sc->stream));
+    sc->pend_params.search = RTMI_SEARCH_CONE_TREE;
+  }
   const DevCounters& hc = *sc->h_cnt;
   float ms_total = 0.f, ms_search = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms_total, sc->ev_a, sc->ev_b));
@@ -1777,6 +2193,8 @@ static int32_t render_end_impl(rtmi_scene* sc, rtmi_counters* counters) {
     counters->tri_exact_tests = (int64_t)sum[C_EXACT];
     counters->primary_hits = (int64_t)sum[C_HITS];
     counters->shadow_rays_elided = (int64_t)sum[C_SHADOW_ELIDED];
+    counters->node_tests = (int64_t)sum[C_NODE_TESTS];
+    counters->tri_candidates = (int64_t)hc.cand_total;
     counters->ms_total = ms_total;
     counters->ms_tri_search = ms_search;
     counters->tri_search_launches = sc->pend_launches;

@@ -1,0 +1,344 @@
+// rtmi_tree.h -- cone tree over a triangle group: the default search of primary rays.
+// Included by rtmi.hip (after its helpers); not a stand-alone translation unit.
+//
+// The reference takes the FIRST hit in list order (RayTracingFunctions.swift:41-43, :83,
+// :86-93).  "First in list order" is the hit with the lowest list position, so the hits of a
+// ray may be found in any order as long as all of them are found and the lowest position is
+// kept.  That frees the search from the list order:
+//
+//   * once per scene the triangles of a group are permuted into spatially compact leaves of
+//     eight (median splits of the centroids); eight consecutive leaves form a level-1 node's
+//     sibling set, eight of those a level-2 node's, and so on: an implicit, left-complete
+//     8-ary tree with no pointers;
+//   * once per frame (k_pack_tree) every triangle that a ray from the camera can hit at all
+//     gets the same cone and edge operands as in the list scan, and every inner node gets a
+//     cone (axis, half-angle) that contains the cones of its children; culled or absent
+//     children have the zero vector (never pass), children wider than about 75 degrees are
+//     flagged "always descend";
+//   * k_search_tree walks the tree once per wave (all R*64 rays of a wave start at the camera
+//     and lie within a few pixels of each other): one record of eight sibling cones is
+//     fetched through scalar loads and evaluated with packed FP32 FMAs exactly like a batch of
+//     the list scan; a child is entered if ANY ray of the wave passes its cone.  At a leaf the
+//     nominated (ray, triangle) pairs go through the edge test and then the FP64 decision
+//     (rtx::tri_hit), and a hit replaces the ray's current one if its list position is lower.
+//
+// A ray that truly hits a triangle has its direction inside that triangle's cone, hence inside
+// the cone of every ancestor, so it reaches the leaf: the filter never loses a hit.
+#pragma once
+
+constexpr int TREE_MAX_LEVELS = 8;  // record levels 0..7: one byte of the traversal word per level
+constexpr int TREE_BLOCK = 512;     // slots per k_pack_tree workgroup: 64 leaves, 8 level-2 nodes, 1 level-3 node
+constexpr int REC_DWORDS = 32;      // per record: 4 pairs x 3 components x 2 children, "always" mask, padding
+constexpr int REC_ALWAYS = 24;      // dword index of the record's "always descend" child mask
+
+struct NodeCone {
+  double ax, ay, az;  // unit axis
+  double c, s;        // cosine and sine of the half-angle
+  int kind;           // 0 empty (nothing below can be hit), 1 cone, 2 wide (always descend)
+  int pad;
+};
+
+struct TreeDev {
+  const int* slot_tri;  // slot -> triangle index, -1 for padding slots
+  const int* slot_pos;  // slot -> position in the group's list order
+  float* rec;           // records of all levels, level 0 first
+  float* edge;          // per slot: EDGE_FLOATS
+  NodeCone* nodes;      // cones of the nodes of levels >= 3 (inputs of the upper merges)
+  unsigned int* ticket; // workgroups of k_pack_tree that have finished their part
+  int n_slots;          // multiple of 8
+  int ltop;             // level of the root record(s)
+  int n_root;           // number of root records (1 unless the group exceeds 8^8 slots)
+  int rec_off[TREE_MAX_LEVELS];        // first record of each level
+  int n_nodes[TREE_MAX_LEVELS + 2];    // nodes per level; level 0 = slots
+  int node_off[TREE_MAX_LEVELS + 2];   // first NodeCone of levels >= 3
+};
+
+// ---------------------------------------------------------------------------------------
+// host: spatial order and level table
+// ---------------------------------------------------------------------------------------
+struct TreeSplitter {
+  const std::vector<std::array<double, 3>>& cen;
+  std::vector<int>& items;     // positions being permuted
+  std::vector<int>& slot_pos;  // result
+  void run(size_t lo, size_t hi, size_t leaf_lo, size_t leaf_cnt) {
+    if (leaf_cnt <= 1) {
+      for (size_t i = lo; i < hi; ++i) slot_pos[leaf_lo * 8 + (i - lo)] = items[i];
+      return;
+    }
+    double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (size_t i = lo; i < hi; ++i)
+      for (int a = 0; a < 3; ++a) {
+        double c = cen[items[i]][a];
+        mn[a] = std::min(mn[a], c);
+        mx[a] = std::max(mx[a], c);
+      }
+    int axis = 0;
+    for (int a = 1; a < 3; ++a)
+      if (mx[a] - mn[a] > mx[axis] - mn[axis]) axis = a;
+    // left part: the largest power of two of whole leaves that leaves something for the right,
+    // so that every aligned run of 8^k leaves is one subtree
+    size_t left_leaves = 1;
+    while (left_leaves * 2 < leaf_cnt) left_leaves *= 2;
+    size_t left_count = left_leaves * 8;
+    std::nth_element(items.begin() + lo, items.begin() + lo + left_count, items.begin() + hi, [&](int a, int b) {
+      double ca = cen[a][axis], cb = cen[b][axis];
+      return ca < cb || (ca == cb && a < b);
+    });
+    run(lo, lo + left_count, leaf_lo, left_leaves);
+    run(lo + left_count, hi, leaf_lo + left_leaves, leaf_cnt - left_leaves);
+  }
+};
+
+struct TreeHost {
+  std::vector<int> slot_pos, slot_tri;
+  TreeDev dev{};
+  size_t n_records = 0, n_node_buf = 0;
+};
+
+// idx: list position -> triangle index
+static void tree_build_host(const rtmi_triangle* tris, const std::vector<int>& idx, TreeHost* th) {
+  const size_t n = idx.size();
+  const size_t n_leaf = std::max<size_t>(1, (n + 7) / 8);
+  th->slot_pos.assign(n_leaf * 8, -1);
+  if (n) {
+    std::vector<std::array<double, 3>> cen(n);
+    for (size_t p = 0; p < n; ++p) {
+      const rtmi_triangle& t = tris[idx[p]];
+      for (int a = 0; a < 3; ++a) {
+        double c = (t.v[0][a] + t.v[1][a] + t.v[2][a]) / 3.0;
+        cen[p][a] = std::isfinite(c) ? c : 0.0;
+      }
+    }
+    std::vector<int> items(n);
+    for (size_t p = 0; p < n; ++p) items[p] = (int)p;
+    TreeSplitter sp{cen, items, th->slot_pos};
+    sp.run(0, n, 0, n_leaf);
+  }
+  th->slot_tri.assign(n_leaf * 8, -1);
+  for (size_t s = 0; s < th->slot_pos.size(); ++s)
+    if (th->slot_pos[s] >= 0) th->slot_tri[s] = idx[th->slot_pos[s]];
+
+  TreeDev& d = th->dev;
+  d.n_slots = (int)(n_leaf * 8);
+  for (int l = 0; l < TREE_MAX_LEVELS + 2; ++l) d.n_nodes[l] = d.node_off[l] = 0;
+  d.n_nodes[0] = d.n_slots;
+  size_t rec = 0, nodes = 0;
+  d.ltop = -1;
+  for (int l = 0; l < TREE_MAX_LEVELS; ++l) {
+    int n_rec = (d.n_nodes[l] + 7) / 8;
+    d.rec_off[l] = (int)rec;
+    if (d.ltop < 0) {
+      rec += (size_t)n_rec;
+      d.n_nodes[l + 1] = n_rec;  // one parent per record
+      if (n_rec == 1 || l == TREE_MAX_LEVELS - 1) {
+        d.ltop = l;
+        d.n_root = n_rec;
+      }
+    }
+  }
+  for (int l = 3; l <= d.ltop + 1; ++l) {
+    d.node_off[l] = (int)nodes;
+    nodes += (size_t)d.n_nodes[l];
+  }
+  th->n_records = rec;
+  th->n_node_buf = std::max<size_t>(nodes, 1);
+}
+
+// ---------------------------------------------------------------------------------------
+// device: per-frame operands
+// ---------------------------------------------------------------------------------------
+// The cone of a node from the cones of its (up to eight) children; *always gets the mask of
+// wide children.  A cone around p with cos(half-angle) <= cos(angle(p, a_k) + theta_k) for every
+// child k contains every child cone; the cross product gives sin(angle) without cancellation.
+__device__ inline NodeCone merge_cones(const NodeCone* ch, int n_valid, unsigned* always) {
+  NodeCone r;
+  r.ax = r.ay = r.az = 0.0;
+  r.c = 1.0;
+  r.s = 0.0;
+  r.kind = 0;
+  r.pad = 0;
+  unsigned wide = 0;
+  bool any = false;
+  d3 sum = rtx::mk(0.0, 0.0, 0.0);
+  for (int k = 0; k < 8; ++k) {
+    int kind = k < n_valid ? ch[k].kind : 0;
+    if (kind == 2) wide |= 1u << k;
+    if (kind == 1) {
+      any = true;
+      sum = rtx::add(sum, rtx::mk(ch[k].ax, ch[k].ay, ch[k].az));
+    }
+  }
+  *always = wide;
+  if (wide) { r.kind = 2; return r; }
+  if (!any) return r;
+  double len = sqrt(rtx::dp(sum, sum));
+  if (!(len > 1.0e-3)) { r.kind = 2; return r; }  // axes cancel (or NaN): no useful cone
+  d3 p = rtx::divs(sum, len);
+  double cmin = 1.0;
+  for (int k = 0; k < 8; ++k) {
+    if (k >= n_valid || ch[k].kind != 1) continue;
+    d3 a = rtx::mk(ch[k].ax, ch[k].ay, ch[k].az);
+    double ca = rtx::dp(p, a);
+    d3 cr = rtx::cross(p, a);
+    double sa = sqrt(rtx::dp(cr, cr));
+    cmin = fmin(cmin, ca * ch[k].c - sa * ch[k].s);  // cos(alpha + theta)
+  }
+  cmin -= 1.0e-12;  // FP64 rounding of the lines above
+  if (!(cmin >= 0.25)) { r.kind = 2; return r; }
+  r.kind = 1;
+  r.ax = p.x; r.ay = p.y; r.az = p.z;
+  r.c = cmin;
+  r.s = sqrt(fmax(0.0, 1.0 - cmin * cmin));
+  return r;
+}
+
+// Address of child j's x component inside a record; y and z follow at +2 and +4.
+__device__ inline float* rec_entry(float* rec, int rec_index, int j) {
+  return rec + (size_t)rec_index * REC_DWORDS + (j >> 1) * 6 + (j & 1);
+}
+
+// Store the FP32 test vector of a node cone: w = axis / (cos - 2^-19), pass iff d.w >= 1 (the
+// margin covers the FP32 evaluation, see k_pack_write); NaN for a wide node, zero for an empty one.
+__device__ inline void store_cone(float* dst, NodeCone* nc) {
+  float wx = 0.f, wy = 0.f, wz = 0.f;
+  if (nc->kind == 1) {
+    double den = nc->c - 1.9073486328125e-06;  // 2^-19
+    wx = (float)(nc->ax / den); wy = (float)(nc->ay / den); wz = (float)(nc->az / den);
+    if (!(den >= 0.0625) || !isfinite(wx) || !isfinite(wy) || !isfinite(wz)) nc->kind = 2;
+  }
+  if (nc->kind == 2) wx = wy = wz = __builtin_nanf("");
+  dst[0] = wx; dst[2] = wy; dst[4] = wz;
+}
+
+// One workgroup per 512 slots: triangle operands, then the three levels above them from LDS;
+// the workgroup that finishes last merges the remaining levels (a few thousand nodes at most
+// for a million triangles).
+__global__ void __launch_bounds__(TREE_BLOCK)
+k_pack_tree(const rtmi_triangle* __restrict__ tris, const TriPlane* __restrict__ planes, TreeDev T, d3 cam) {
+  __shared__ NodeCone l0[TREE_BLOCK];
+  __shared__ NodeCone l1[TREE_BLOCK / 8];
+  __shared__ NodeCone l2[TREE_BLOCK / 64];
+  __shared__ int is_last;
+  const int tid = threadIdx.x;
+  const int p = blockIdx.x * TREE_BLOCK + tid;
+  NodeCone nc;
+  nc.ax = nc.ay = nc.az = 0.0; nc.c = 1.0; nc.s = 0.0; nc.kind = 0; nc.pad = 0;
+  if (p < T.n_slots) {
+    const int ti = T.slot_tri[p];
+    float e9[EDGE_FLOATS];
+    for (int q = 0; q < EDGE_FLOATS; ++q) e9[q] = 0.f;
+    bool keep = false;
+    if (ti >= 0) {
+      // t > 0 is ray-independent for a common origin (Renderables.swift:150-152): keep iff num < 0
+      const TriPlane pl = planes[ti];
+      double num = pl.c - rtx::dp(rtx::mk(pl.nx, pl.ny, pl.nz), cam);
+      keep = num < 0;  // false for NaN (degenerate triangle): never hit in the reference either
+    }
+    if (keep) {
+      const rtmi_triangle& t = tris[ti];
+      d3 A = rtx::sub(rtx::ld3(t.v[0]), cam), B = rtx::sub(rtx::ld3(t.v[1]), cam), Cc = rtx::sub(rtx::ld3(t.v[2]), cam);
+      double la = sqrt(rtx::dp(A, A)), lb = sqrt(rtx::dp(B, B)), lc = sqrt(rtx::dp(Cc, Cc));
+      d3 a = rtx::divs(A, la), bb = rtx::divs(B, lb), c = rtx::divs(Cc, lc);
+      d3 sum = rtx::add(rtx::add(a, bb), c);
+      double ls = sqrt(rtx::dp(sum, sum));
+      d3 axis = rtx::divs(sum, ls);
+      double cos_t = fmin(rtx::dp(axis, a), fmin(rtx::dp(axis, bb), rtx::dp(axis, c)));
+      if (cos_t - 1.9073486328125e-06 >= 0.0625) {  // false for NaN too
+        nc.kind = 1;
+        nc.ax = axis.x; nc.ay = axis.y; nc.az = axis.z;
+        nc.c = cos_t;
+        nc.s = sqrt(fmax(0.0, 1.0 - cos_t * cos_t));
+      } else {
+        nc.kind = 2;
+      }
+      // edge planes, as in k_pack_write
+      d3 M[3] = {rtx::cross(A, B), rtx::cross(B, Cc), rtx::cross(Cc, A)};
+      double L = fabs(cam.x) + fabs(cam.y) + fabs(cam.z);
+      double lv = 0;
+      for (int q = 0; q < 3; ++q) lv = fmax(lv, fabs(t.v[q][0]) + fabs(t.v[q][1]) + fabs(t.v[q][2]));
+      L += lv;
+      const double eps32 = 5.9604644775390625e-08;    // 2^-24
+      const double abs_term = 9.094947017729282e-13;  // 2^-40
+      for (int e = 0; e < 3; ++e) {
+        double E = 16.0 * eps32 * (fabs(M[e].x) + fabs(M[e].y) + fabs(M[e].z)) + abs_term * L * L;
+        float mx = (float)(M[e].x / E), my = (float)(M[e].y / E), mz = (float)(M[e].z / E);
+        if (!(E > 0) || !isfinite(mx) || !isfinite(my) || !isfinite(mz)) mx = my = mz = 0.0f;  // always nominate
+        e9[e * 3 + 0] = mx; e9[e * 3 + 1] = my; e9[e * 3 + 2] = mz;
+      }
+    }
+    store_cone(rec_entry(T.rec, T.rec_off[0] + (p >> 3), p & 7), &nc);
+    float* ed = T.edge + (size_t)p * EDGE_FLOATS;
+    for (int q = 0; q < EDGE_FLOATS; ++q) ed[q] = e9[q];
+  }
+  l0[tid] = nc;
+  __syncthreads();
+
+  // Level L nodes (L = 1, 2, 3) of this workgroup: node j merges the eight nodes of record
+  // (L-1, j); the record gets its "always" mask, and the node's own cone goes into record (L, j/8)
+  // if that level exists.
+  NodeCone empty = nc;
+  empty.kind = 0;
+  {
+    const int g1 = blockIdx.x * (TREE_BLOCK / 8) + tid;
+    if (tid < TREE_BLOCK / 8) {
+      NodeCone m = empty;
+      if (1 <= T.ltop + 1 && g1 < T.n_nodes[1]) {
+        unsigned always;
+        m = merge_cones(&l0[tid * 8], 8, &always);
+        if (1 <= T.ltop) store_cone(rec_entry(T.rec, T.rec_off[1] + (g1 >> 3), g1 & 7), &m);
+        reinterpret_cast<unsigned*>(T.rec)[(size_t)(T.rec_off[0] + g1) * REC_DWORDS + REC_ALWAYS] = always;
+      }
+      l1[tid] = m;
+    }
+  }
+  __syncthreads();
+  {
+    const int g2 = blockIdx.x * (TREE_BLOCK / 64) + tid;
+    if (tid < TREE_BLOCK / 64) {
+      NodeCone m = empty;
+      if (2 <= T.ltop + 1 && g2 < T.n_nodes[2]) {
+        unsigned always;
+        m = merge_cones(&l1[tid * 8], 8, &always);
+        if (2 <= T.ltop) store_cone(rec_entry(T.rec, T.rec_off[2] + (g2 >> 3), g2 & 7), &m);
+        reinterpret_cast<unsigned*>(T.rec)[(size_t)(T.rec_off[1] + g2) * REC_DWORDS + REC_ALWAYS] = always;
+      }
+      l2[tid] = m;
+    }
+  }
+  __syncthreads();
+  if (T.ltop + 1 < 3) return;
+  if (tid == 0) {
+    const int g3 = blockIdx.x;
+    if (g3 < T.n_nodes[3]) {
+      unsigned always;
+      NodeCone m = merge_cones(l2, 8, &always);
+      if (3 <= T.ltop) store_cone(rec_entry(T.rec, T.rec_off[3] + (g3 >> 3), g3 & 7), &m);
+      reinterpret_cast<unsigned*>(T.rec)[(size_t)(T.rec_off[2] + g3) * REC_DWORDS + REC_ALWAYS] = always;
+      T.nodes[T.node_off[3] + g3] = m;
+    }
+    __threadfence();
+    is_last = atomicAdd(T.ticket, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!is_last || T.ltop + 1 < 4) {
+    if (is_last && tid == 0) *T.ticket = 0;
+    return;
+  }
+  __threadfence();
+  for (int L = 4; L <= T.ltop + 1; ++L) {
+    for (int j = tid; j < T.n_nodes[L]; j += TREE_BLOCK) {
+      NodeCone ch[8];
+      int nv = min(8, T.n_nodes[L - 1] - j * 8);
+      for (int k = 0; k < 8; ++k)
+        if (k < nv) ch[k] = T.nodes[T.node_off[L - 1] + j * 8 + k];
+      unsigned always;
+      NodeCone m = merge_cones(ch, nv, &always);
+      if (L <= T.ltop) store_cone(rec_entry(T.rec, T.rec_off[L] + (j >> 3), j & 7), &m);
+      reinterpret_cast<unsigned*>(T.rec)[(size_t)(T.rec_off[L - 1] + j) * REC_DWORDS + REC_ALWAYS] = always;
+      T.nodes[T.node_off[L] + j] = m;
+    }
+    __threadfence();
+    __syncthreads();
+  }
+  if (tid == 0) *T.ticket = 0;
+}

@@ -19,17 +19,25 @@ pytestmark = pytest.mark.gpu
 
 
 def assert_parity(oracle_mod, rt, data, cam, params, threads=16):
+    """Both search strategies (cone tree, list scan) against the oracle; returns the oracle's and the
+    cone tree's counters."""
+    import copy
     o_rgba, o_hit, o_cnt = oracle_mod.render(data, cam, params, threads=threads)
     sc = rt.Scene(data)
-    g_rgba, g_hit, g_cnt = sc.render(cam, params)
+    first = None
+    for search in (_abi.RTMI_SEARCH_CONE_TREE, _abi.RTMI_SEARCH_LIST_SCAN):
+        p = copy.copy(params)
+        p.search = search
+        g_rgba, g_hit, g_cnt = sc.render(cam, p)
+        assert (g_hit == o_hit).all(), f"search {search}: {int((g_hit != o_hit).sum())} hit-id mismatches of {o_hit.size}"
+        diff = np.abs(g_rgba.astype(int) - o_rgba.astype(int))
+        assert diff.max() <= 1
+        assert int((diff > 0).sum()) == 0
+        for k in ("samples", "rays_reflection", "rays_shadow", "sphere_tests", "primary_hits"):
+            assert g_cnt[k] == o_cnt[k], (search, k)
+        first = first or g_cnt
     sc.close()
-    assert (g_hit == o_hit).all(), f"{int((g_hit != o_hit).sum())} hit-id mismatches of {o_hit.size}"
-    diff = np.abs(g_rgba.astype(int) - o_rgba.astype(int))
-    assert diff.max() <= 1
-    assert int((diff > 0).sum()) == 0
-    for k in ("samples", "rays_reflection", "rays_shadow", "sphere_tests", "primary_hits"):
-        assert g_cnt[k] == o_cnt[k], k
-    return o_cnt, g_cnt
+    return o_cnt, first
 
 
 def random_soup(rng, n, scale=1.0, spread=1.5):
@@ -232,6 +240,26 @@ def test_config4_1_3m_triangles_full_frame_windows(oracle_mod, rt):
         o_rgba, o_hit, _ = oracle_mod.render(data, cam, scenes.make_params(1920, 1080, 0.5, window=win), threads=16)
         assert (o_hit[y0:y1, x0:x1] == fhit[y0:y1, x0:x1]).all()
         assert int(np.abs(o_rgba[y0:y1, x0:x1].astype(int) - full[y0:y1, x0:x1].astype(int)).max()) <= 1
+
+
+def test_deep_stack_of_overlapping_triangles(oracle_mod, rt):
+    """Every ray passes the cones of 300 stacked triangles: far more candidate pairs than the cone
+    tree's list holds, so the library falls back to the list scan for the frame; the result is
+    the same either way (lowest list position wins: the triangle listed first, not the nearest)."""
+    n = 300
+    tris = np.zeros(n, scenes.TRI_DTYPE)
+    z = np.linspace(-1.0, 1.0, n)
+    rng = np.random.default_rng(5)
+    order = rng.permutation(n)
+    for i, k in enumerate(order):
+        tris["v"][i] = [[-3.0, -3.0, z[k]], [3.0, -3.0, z[k]], [0.0, 4.0, z[k]]]
+    tris["material"] = 0
+    c, r = rt.bounding_sphere(tris)
+    data = scenes.SceneData(lights=three_lights(), materials=TWO_MATS,
+                            objects=scenes.sphere_object(c, r, -1, bounding=True, first=0, count=n), triangles=tris)
+    cam = scenes.make_camera(**scenes.MESH_CAMERA)
+    o, g = assert_parity(oracle_mod, rt, data, cam, scenes.make_params(64, 64, 0.5))
+    assert o["primary_hits"] > 0
 
 
 def test_render_errors(rt):
