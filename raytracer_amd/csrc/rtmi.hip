@@ -92,7 +92,9 @@ struct DevCounters {
   // The tree search keeps NSLOT candidate lists (a wave appends to list `wave & 63`), each with its
   // fill level on a cache line of its own: returning atomics on ONE address complete at roughly
   // one per 30 ns, which a launch of 200,000 waves cannot afford.
-  int cand_n[NSLOT][16];
+  // Two sets, used alternately by successive search launches of a frame: the last kernel of a
+  // launch clears the set of the launch before it.
+  int cand_n[2][NSLOT][16];
 };
 
 struct SceneDev {
@@ -966,13 +968,23 @@ __device__ __forceinline__ unsigned tree_eval(const f2* __restrict__ rp, const f
   return (unsigned)__builtin_amdgcn_readfirstlane((int)mask);
 }
 
+// Called by the last kernel of a tree search launch (any one workgroup's first NSLOT threads do
+// the work): add this launch's candidate counts to the frame total and clear the OTHER set of
+// list counters, which the launch before this one used and the next one will use.
+__device__ inline void search_lists_retire(DevCounters* cnt, int parity) {
+  if (blockIdx.x == 0 && threadIdx.x < NSLOT) {
+    atomicAdd(&cnt->cand_total, (unsigned long long)(unsigned int)cnt->cand_n[parity][threadIdx.x][0]);
+    cnt->cand_n[parity ^ 1][threadIdx.x][0] = 0;
+  }
+}
+
 // Hand the wave's staged candidates to its global list: one returning atomic per flush.
-__device__ __forceinline__ void cand_flush(const SearchArgs* ap, const int2* stage, int fill, int lane, int list) {
+__device__ __forceinline__ void cand_flush(const SearchArgs* ap, const int2* stage, int fill, int lane, int list, int parity) {
   if (fill == 0) return;
   DevCounters* cnt = ap->cnt;
   const int list_cap = ap->cand_cap / NSLOT;
   int base = 0;
-  if (lane == 0) base = atomicAdd(&cnt->cand_n[list][0], fill);
+  if (lane == 0) base = atomicAdd(&cnt->cand_n[parity][list][0], fill);
   base = __builtin_amdgcn_readfirstlane(base);
   if (base + fill > list_cap || base < 0) {
     if (lane == 0) cnt->overflow = 1;  // the caller renders this frame again with the list scan
@@ -989,7 +1001,7 @@ __device__ __forceinline__ void cand_flush(const SearchArgs* ap, const int2* sta
 // pushed but evaluated per lane: every (ray, slot) pair that passes becomes a candidate.
 template <int R>
 __global__ void __launch_bounds__(256)
-k_search_tree(const SearchArgs* __restrict__ ap, const f2* __restrict__ rec, const float* __restrict__ edge_all) {
+k_search_tree(const SearchArgs* __restrict__ ap, const f2* __restrict__ rec, const float* __restrict__ edge_all, int parity) {
   __shared__ int2 stage_all[4][CAND_STAGE];
   const int nq = *ap->nq_ptr;
   const int lane = threadIdx.x & 63;
@@ -1066,7 +1078,7 @@ k_search_tree(const SearchArgs* __restrict__ ap, const f2* __restrict__ rec, con
         if (bm == 0) continue;
         const int n = __popcll(bm);
         if (fill + n > CAND_STAGE) {
-          cand_flush(ap, stage, fill, lane, wave & (NSLOT - 1));
+          cand_flush(ap, stage, fill, lane, wave & (NSLOT - 1), parity);
           fill = 0;
           __builtin_amdgcn_wave_barrier();
         }
@@ -1111,7 +1123,7 @@ k_search_tree(const SearchArgs* __restrict__ ap, const f2* __restrict__ rec, con
     }
   }
   __builtin_amdgcn_wave_barrier();
-  cand_flush(ap, stage, fill, lane, wave & (NSLOT - 1));
+  cand_flush(ap, stage, fill, lane, wave & (NSLOT - 1), parity);
 
   // work counters: (ray, triangle) cone tests at leaf level, (ray, node) tests above it
   int active = 0;
@@ -1126,13 +1138,13 @@ k_search_tree(const SearchArgs* __restrict__ ap, const f2* __restrict__ rec, con
 // lowest list position.  Workgroup w serves candidate list w & 63 together with the other
 // workgroups of that residue (the grid is a multiple of 64 workgroups).
 __global__ void __launch_bounds__(256)
-k_search_exact(const SearchArgs* __restrict__ ap) {
+k_search_exact(const SearchArgs* __restrict__ ap, int parity) {
   const DevCounters* cnt = ap->cnt;
   unsigned int n_exact = 0;
   if (!cnt->overflow) {  // after an overflow the lists are incomplete and the frame is rendered again
     const int list = blockIdx.x & (NSLOT - 1), part = blockIdx.x / NSLOT, parts = gridDim.x / NSLOT;
     const int list_cap = ap->cand_cap / NSLOT;
-    const int n = cnt->cand_n[list][0];
+    const int n = cnt->cand_n[parity][list][0];
     const int2* cand = ap->cand + (size_t)list * list_cap;
     const double* dirs = ap->dirs;
     const d3 o = rtx::ld3(ap->cam);
@@ -1154,72 +1166,28 @@ k_search_exact(const SearchArgs* __restrict__ ap) {
   wave_count(ap->cnt, C_EXACT, (unsigned long long)n_exact);
 }
 
-// One lane per ray of the launch's queue: the lowest list position that was hit -> triangle
-// index, t (the same FP64 evaluation once more: it is deterministic) and the shade queue.
-// Persistent workgroups: each walks the queue in 256-ray steps and collects its hits in LDS, so
-// that the shade queue's fill level sees one returning atomic per FINISH_STAGE hits, not one per step.
-constexpr int FINISH_STAGE = 8192;
+// Top-level runs only (mode 1): one lane per ray of the queue, lowest list position that was
+// hit -> triangle index in tri_hit[q] for k_resolve_top, and the hit's t.
 __global__ void __launch_bounds__(256)
-k_search_finish(const SearchArgs* __restrict__ ap) {
-  __shared__ int stage[FINISH_STAGE];
-  __shared__ int wtot[2][4];  // per-wave hit counts of the current step, double-buffered by step parity
-  __shared__ int gbase;
+k_search_finish(const SearchArgs* __restrict__ ap, int parity) {
   const int nq = *ap->nq_ptr;
-  DevCounters* cnt = ap->cnt;
-  if (blockIdx.x == 0 && threadIdx.x < NSLOT) {  // k_search_exact is done with the candidate lists
-    atomicAdd(&cnt->cand_total, (unsigned long long)(unsigned int)cnt->cand_n[threadIdx.x][0]);
-    cnt->cand_n[threadIdx.x][0] = 0;
+  search_lists_retire(ap->cnt, parity);
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  const int s = ap->queue[q];
+  int ti = -1;
+  const int pos = ap->best_pos[s];
+  if (pos != 0x7fffffff) {
+    ti = ap->group[pos];
+    const rtmi_triangle& tr = ap->tris[ti];
+    const double* dp = ap->dirs + (size_t)s * 3;
+    d3 P;
+    double tv = 0.0;
+    rtx::tri_hit(rtx::ld3(tr.v[0]), rtx::ld3(tr.v[1]), rtx::ld3(tr.v[2]), ap->planes[ti], rtx::ld3(ap->cam),
+                 rtx::mk(dp[0], dp[1], dp[2]), &tv, &P);
+    ap->tval[s] = tv;  // the hit point is origin + t*direction; shading rebuilds it
   }
-  const int mode = ap->mode;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  // `fill` is kept in a register by every thread and updated identically by all of them, so the
-  // decision to flush is the same in every wave (a shared counter would be read by a slow wave
-  // after a fast wave had already added this step's hits to it).
-  int fill = 0, parity = 0;
-  auto flush = [&]() {  // reached by all threads of the workgroup, or by none
-    if (threadIdx.x == 0) gbase = fill ? atomicAdd(&cnt->q_shade, fill) : 0;
-    __syncthreads();  // gbase is visible; every wave has finished writing its staged hits
-    int* q_shade = ap->q_shade + gbase;
-    for (int i = threadIdx.x; i < fill; i += blockDim.x) q_shade[i] = stage[i];
-    __syncthreads();  // the stage may be overwritten from here on
-    fill = 0;
-  };
-  for (int q0 = blockIdx.x * blockDim.x; q0 < nq; q0 += gridDim.x * blockDim.x) {
-    const int q = q0 + threadIdx.x;
-    const bool valid = q < nq;
-    int s = valid ? ap->queue[q] : -1;
-    if (valid && mode == 0 && ap->hit_id[s] != -2 - ap->obj_filter) s = -1;
-    int ti = -1;
-    if (s >= 0) {
-      const int pos = ap->best_pos[s];
-      if (pos != 0x7fffffff) {
-        ti = ap->group[pos];
-        const rtmi_triangle& tr = ap->tris[ti];
-        const double* dp = ap->dirs + (size_t)s * 3;
-        d3 P;
-        double tv = 0.0;
-        rtx::tri_hit(rtx::ld3(tr.v[0]), rtx::ld3(tr.v[1]), rtx::ld3(tr.v[2]), ap->planes[ti], rtx::ld3(ap->cam),
-                     rtx::mk(dp[0], dp[1], dp[2]), &tv, &P);
-        ap->tval[s] = tv;  // the hit point is origin + t*direction; shading rebuilds it
-      }
-    }
-    if (mode == 0) {
-      if (s >= 0) ap->hit_id[s] = ti;
-      if (fill + (int)blockDim.x > FINISH_STAGE) flush();
-      const bool hit = s >= 0 && ti >= 0;
-      const unsigned long long m = __ballot(hit);
-      if (lane == 0) wtot[parity][w] = __popcll(m);
-      __syncthreads();
-      int pos = fill;
-      for (int k = 0; k < w; ++k) pos += wtot[parity][k];
-      if (hit) stage[pos + __popcll(m & ((1ull << lane) - 1ull))] = s;
-      fill += wtot[parity][0] + wtot[parity][1] + wtot[parity][2] + wtot[parity][3];
-      parity ^= 1;  // the next step writes the other half: a slow wave may still be reading this one
-    } else if (valid) {
-      ap->tri_hit[q] = ti;
-    }
-  }
-  if (mode == 0) flush();
+  ap->tri_hit[q] = ti;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1354,6 +1322,65 @@ __device__ RGBd calculate_lighting(const SceneDev& sc, const ShadeConst& fc, con
   return I;
 }
 
+// Work tallies of a shading lane, summed per wave at the end of the kernel.
+struct ShadeTally {
+  unsigned long long n_refl = 0, n_shadow = 0, n_hit = 0, n_tests = 0, n_elided = 0;
+};
+
+__device__ inline void shade_tally_flush(DevCounters* cnt, const ShadeTally& t) {
+  wave_count(cnt, C_HITS, t.n_hit);
+  wave_count(cnt, C_REFL, t.n_refl);
+  wave_count(cnt, C_SHADOW, t.n_shadow);
+  wave_count(cnt, C_TESTS_SECONDARY, t.n_tests);
+  wave_count(cnt, C_SHADOW_ELIDED, t.n_elided);
+}
+
+// Shade sample s whose primary ray (direction d) hit `id` (triangle index, or -2 - object index);
+// t_tri is the triangle's intersection parameter.
+template <bool HAS_TOP>
+__device__ __forceinline__ void shade_sample(const ShadeConst& fc, const SceneDev& sc, int s, d3 d, int id, double t_tri,
+                                             double* rgb, ShadeTally* tl) {
+  d3 cam = rtx::ld3(fc.cam);
+  Hit h;
+  bool ok = false;
+  if (id >= 0) {
+    const rtmi_triangle& tr = sc.tris[id];
+    const TriPlane pl = sc.planes[id];
+    // the search already decided this hit with Triangle.intersections; rebuild its point
+    // exactly as Renderables.swift:153 does: origin + intersectionParameter * direction
+    ok = true;
+    h.t = t_tri;
+    h.P = rtx::add(cam, rtx::smul(h.t, d));
+    h.n = rtx::mk(pl.nx, pl.ny, pl.nz);
+    h.has_normal = 1;
+    h.n_unit = 1;
+    h.material = tr.material;
+    h.id = id;
+  } else {
+    const rtmi_object& ob = sc.objects[-2 - id];
+    if (ob.kind == RTMI_LIGHT) {
+      ok = rtx::light_hit(rtx::ld3(sc.lights[ob.first].loc), cam, d, &h.t, &h.P);
+      h.has_normal = 0;
+      h.n_unit = 1;
+      h.material = -1;
+    } else {
+      ok = rtx::sphere_first(rtx::ld3(ob.center), ob.radius, cam, d, &h.t, &h.P, &h.n);
+      h.has_normal = 1;
+      h.n_unit = 1;
+      h.material = ob.material;
+    }
+    h.id = id;
+  }
+  RGBd c = {0.0, 0.0, 0.0};
+  if (ok) {
+    tl->n_hit += 1;
+    c = calculate_lighting<true, HAS_TOP>(sc, fc, h, cam, &tl->n_refl, &tl->n_shadow, &tl->n_tests, &tl->n_elided);
+  }
+  rgb[(size_t)s * 3 + 0] = c.r;
+  rgb[(size_t)s * 3 + 1] = c.g;
+  rgb[(size_t)s * 3 + 2] = c.b;
+}
+
 // HAS_TOP: the scene lists triangles at top level, so secondary rays scan them (the code of
 // that scan is left out of the instantiation for scenes without such runs).
 template <bool HAS_TOP>
@@ -1361,57 +1388,51 @@ __global__ void __launch_bounds__(256)
 k_shade(ShadeConst fc, SceneDev sc, const double* __restrict__ dirs,
         const double* __restrict__ tval, const int* __restrict__ q_shade,
         const int* __restrict__ nq_ptr, const int* __restrict__ hit_id, double* rgb, DevCounters* cnt) {
-  int q = blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned long long n_refl = 0, n_shadow = 0, n_hit = 0, n_tests = 0, n_elided = 0;
-  if (q < *nq_ptr) {
+  ShadeTally tl;
+  const int nq = *nq_ptr;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
     int s = q_shade[q];
     d3 d = rtx::mk(dirs[(size_t)s * 3 + 0], dirs[(size_t)s * 3 + 1], dirs[(size_t)s * 3 + 2]);
-    d3 cam = rtx::ld3(fc.cam);
     int id = hit_id[s];
-    Hit h;
-    bool ok = false;
-    if (id >= 0) {
-      const rtmi_triangle& tr = sc.tris[id];
-      const TriPlane pl = sc.planes[id];
-      // the search already decided this hit with Triangle.intersections; rebuild its point
-      // exactly as Renderables.swift:153 does: origin + intersectionParameter * direction
-      ok = true;
-      h.t = tval[s];
-      h.P = rtx::add(cam, rtx::smul(h.t, d));
-      h.n = rtx::mk(pl.nx, pl.ny, pl.nz);
-      h.has_normal = 1;
-      h.n_unit = 1;
-      h.material = tr.material;
-      h.id = id;
-    } else {
-      const rtmi_object& ob = sc.objects[-2 - id];
-      if (ob.kind == RTMI_LIGHT) {
-        ok = rtx::light_hit(rtx::ld3(sc.lights[ob.first].loc), cam, d, &h.t, &h.P);
-        h.has_normal = 0;
-        h.n_unit = 1;
-        h.material = -1;
-      } else {
-        ok = rtx::sphere_first(rtx::ld3(ob.center), ob.radius, cam, d, &h.t, &h.P, &h.n);
-        h.has_normal = 1;
-        h.n_unit = 1;
-        h.material = ob.material;
-      }
-      h.id = id;
-    }
-    RGBd c = {0.0, 0.0, 0.0};
-    if (ok) {
-      n_hit = 1;
-      c = calculate_lighting<true, HAS_TOP>(sc, fc, h, cam, &n_refl, &n_shadow, &n_tests, &n_elided);
-    }
-    rgb[(size_t)s * 3 + 0] = c.r;
-    rgb[(size_t)s * 3 + 1] = c.g;
-    rgb[(size_t)s * 3 + 2] = c.b;
+    shade_sample<HAS_TOP>(fc, sc, s, d, id, id >= 0 ? tval[s] : 0.0, rgb, &tl);
   }
-  wave_count(cnt, C_HITS, n_hit);
-  wave_count(cnt, C_REFL, n_refl);
-  wave_count(cnt, C_SHADOW, n_shadow);
-  wave_count(cnt, C_TESTS_SECONDARY, n_tests);
-  wave_count(cnt, C_SHADOW_ELIDED, n_elided);
+  shade_tally_flush(cnt, tl);
+}
+
+// The cone tree's last stage for the children of a bounding object: one lane per candidate
+// (grid-stride over the NSLOT lists, like k_search_exact).  The candidate whose list position is
+// the ray's lowest hit -- k_search_exact has settled that -- is the ray's intersection: its
+// triangle index goes to hit_id and the sample is shaded here, without a detour through the
+// shade queue.  t comes from the same FP64 evaluation once more (it is deterministic).  Samples
+// without a hit keep the bounding object's marker in hit_id; k_resolve reads that as a miss.
+template <bool HAS_TOP>
+__global__ void __launch_bounds__(256)
+k_shade_candidates(ShadeConst fc, SceneDev sc, const SearchArgs* __restrict__ ap, double* rgb, int par) {
+  DevCounters* cnt = ap->cnt;
+  ShadeTally tl;
+  if (!cnt->overflow) {
+    const int list = blockIdx.x & (NSLOT - 1), part = blockIdx.x / NSLOT, parts = gridDim.x / NSLOT;
+    const int list_cap = ap->cand_cap / NSLOT;
+    const int n = cnt->cand_n[par][list][0];
+    const int2* cand = ap->cand + (size_t)list * list_cap;
+    const double* dirs = ap->dirs;
+    for (int i = part * blockDim.x + threadIdx.x; i < n; i += parts * blockDim.x) {
+      const int2 c = cand[i];
+      const int s = c.x, g = c.y;
+      if (ap->best_pos[s] != ap->tree.slot_pos[g]) continue;  // another triangle of this ray is listed earlier, or no hit
+      const int ti = ap->tree.slot_tri[g];
+      const double* dp = dirs + (size_t)s * 3;
+      const d3 d = rtx::mk(dp[0], dp[1], dp[2]);
+      const rtmi_triangle& tr = sc.tris[ti];
+      d3 P;
+      double tv = 0.0;
+      rtx::tri_hit(rtx::ld3(tr.v[0]), rtx::ld3(tr.v[1]), rtx::ld3(tr.v[2]), sc.planes[ti], rtx::ld3(fc.cam), d, &tv, &P);
+      ap->hit_id[s] = ti;
+      shade_sample<HAS_TOP>(fc, sc, s, d, ti, tv, rgb, &tl);
+    }
+  }
+  search_lists_retire(cnt, par);
+  shade_tally_flush(cnt, tl);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1420,7 +1441,7 @@ k_shade(ShadeConst fc, SceneDev sc, const double* __restrict__ dirs,
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_resolve(FrameConst fc, const int2* __restrict__ blocks, int npix, const int* __restrict__ hit_id,
-          const double* __restrict__ rgb, unsigned char* rgba, int* hit_out) {
+          const double* __restrict__ rgb, const rtmi_object* __restrict__ objects, unsigned char* rgba, int* hit_out) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= npix) return;
   int b = p >> 6, pix = p & (BLK_PIX - 1);
@@ -1430,6 +1451,8 @@ k_resolve(FrameConst fc, const int2* __restrict__ blocks, int npix, const int* _
   for (int q = 0; q < fc.spp; ++q) {
     int s = ((b * fc.spp + q) << 6) + pix;
     int id = hit_id[s];
+    // a bounding object's marker that no child hit has replaced: the ray hit nothing (RTF:86-93)
+    if (id <= -2 && objects[-2 - id].kind == RTMI_BOUNDING_SPHERE) id = -1;
     double r = 0.0, g = 0.0, bl = 0.0;  // RGB.black for a miss
     if (id != -1) {
       r = rgb[(size_t)s * 3 + 0];
@@ -2067,6 +2090,8 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
   for (int a = 0; a < 3; ++a) { shc.cam[a] = fc.cam[a]; shc.ambient[a] = fc.ambient[a]; }
 
   long long launches = 0;
+  int launch_parity = 0;  // tree search launches of the frame alternate between two sets of list counters
+  const bool has_top_runs = sc->groups[0].n > 0;
   sc->ev_used = 0;
   auto next_events = [&](hipEvent_t* e0, hipEvent_t* e1) -> int32_t {
     if (sc->ev_used == sc->ev_pool.size()) {
@@ -2101,10 +2126,16 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
       if (rc2) return rc2;
       HIP_TRY(hipEventRecord(e0, st));
       if (use_tree) {
+        const int par = launch_parity;
+        launch_parity ^= 1;
         hipLaunchKernelGGL(tree_kernel, dim3(search_grid), dim3(256), 0, st, sc->d_sargs + gi, (const f2*)g.d_rec,
-                           (const float*)g.d_tedge);
-        hipLaunchKernelGGL(k_search_exact, dim3(sc->exact_grid), dim3(256), 0, st, sc->d_sargs + gi);
-        hipLaunchKernelGGL(k_search_finish, dim3(std::min(grid, sc->exact_grid)), dim3(256), 0, st, sc->d_sargs + gi);
+                           (const float*)g.d_tedge, par);
+        hipLaunchKernelGGL(k_search_exact, dim3(sc->exact_grid), dim3(256), 0, st, sc->d_sargs + gi, par);
+        if (gi == 0)
+          hipLaunchKernelGGL(k_search_finish, dim3(grid), dim3(256), 0, st, sc->d_sargs + gi, par);
+        else
+          hipLaunchKernelGGL(has_top_runs ? k_shade_candidates<true> : k_shade_candidates<false>, dim3(sc->exact_grid), dim3(256),
+                             0, st, shc, sc->dev, sc->d_sargs + gi, sc->d_rgb, par);
       } else {
         hipLaunchKernelGGL(scan_kernel, dim3(search_grid), dim3(256), 0, st, sc->d_sargs + gi, (const f2*)g.d_cone);
       }
@@ -2119,11 +2150,11 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
     }
     for (size_t gi = 1; gi < sc->groups.size(); ++gi)
       if ((rc = search_group(gi))) return rc;
-    hipLaunchKernelGGL(sc->groups[0].n > 0 ? k_shade<true> : k_shade<false>, dim3(grid), dim3(256), 0, st, shc, sc->dev, sc->d_dirs, sc->d_tval, sc->d_q_shade, &sc->d_cnt->q_shade,
+    hipLaunchKernelGGL(has_top_runs ? k_shade<true> : k_shade<false>, dim3(std::min(grid, 4 * sc->exact_grid)), dim3(256), 0, st, shc, sc->dev, sc->d_dirs, sc->d_tval, sc->d_q_shade, &sc->d_cnt->q_shade,
                        sc->d_hit_id, sc->d_rgb, sc->d_cnt);
     int npix = (int)(nb * BLK_PIX);
     hipLaunchKernelGGL(k_resolve, dim3((npix + 255) / 256), dim3(256), 0, st, fc, d_blk, npix, sc->d_hit_id, sc->d_rgb,
-                       (unsigned char*)rgba_dev, (int*)hit_dev);
+                       (const rtmi_object*)sc->d_objects, (unsigned char*)rgba_dev, (int*)hit_dev);
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipEventRecord(sc->ev_b, st));
