@@ -527,6 +527,7 @@ template <bool HAS_TOP>
 __device__ inline bool trace_top_secondary(const SceneDev& sc, d3 o, d3 d, bool want_first, Hit* h,
                                            bool* any_non_bounding, unsigned long long* n_tests) {
   bool found = false, anb = false;
+#pragma nounroll
   for (int k = 0; k < sc.n_objects; ++k) {
     if (want_first ? found : anb) break;
     const rtmi_object& ob = sc.objects[k];
@@ -1000,7 +1001,7 @@ __device__ __forceinline__ void cand_flush(const SearchArgs* ap, const int2* sta
 // (l, j) are record (l-1, j); level-0 nodes are triangle slots, and a level-0 record is not
 // pushed but evaluated per lane: every (ray, slot) pair that passes becomes a candidate.
 template <int R>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 6)
 k_search_tree(const SearchArgs* __restrict__ ap, const f2* __restrict__ rec, const float* __restrict__ edge_all, int parity) {
   __shared__ int2 stage_all[4][CAND_STAGE];
   const int nq = *ap->nq_ptr;
@@ -1293,6 +1294,7 @@ __device__ RGBd calculate_lighting(const SceneDev& sc, const ShadeConst& fc, con
     I.r = rtx::clamp01(I.r); I.g = rtx::clamp01(I.g); I.b = rtx::clamp01(I.b);  // RTF:269
     return I;
   }
+#pragma nounroll
   for (int li = 0; li < sc.n_lights; ++li) {  // RTF:226-268
     const rtmi_light& light = sc.lights[li];
     d3 point_to_light = rtx::normalize(rtx::sub(rtx::ld3(light.loc), surface_point));
@@ -1406,7 +1408,7 @@ k_shade(ShadeConst fc, SceneDev sc, const double* __restrict__ dirs,
 // shade queue.  t comes from the same FP64 evaluation once more (it is deterministic).  Samples
 // without a hit keep the bounding object's marker in hit_id; k_resolve reads that as a miss.
 template <bool HAS_TOP>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, HAS_TOP ? 2 : 4)
 k_shade_candidates(ShadeConst fc, SceneDev sc, const SearchArgs* __restrict__ ap, double* rgb, int par) {
   DevCounters* cnt = ap->cnt;
   ShadeTally tl;
@@ -1492,6 +1494,9 @@ struct TriGroup {
   float* d_tedge = nullptr;
   NodeCone* d_nodes = nullptr;
   unsigned int* d_ticket = nullptr;
+  // which operands the device holds: 0 none, 1 cone tree, 2 list scan -- and for which camera position
+  int packed_for = 0;
+  double packed_cam[3] = {0, 0, 0};
 };
 
 struct rtmi_scene {
@@ -1524,19 +1529,20 @@ struct rtmi_scene {
   double* d_tval = nullptr;
   int* d_best_pos = nullptr;   // tree search: per sample, lowest list position hit
   int2* d_cand = nullptr;      // tree search: candidate pairs, cap_samples entries
-  FrameConst* d_fc = nullptr;
-  FrameConst h_fc{};
-  SceneDev* d_scdev = nullptr;       // device copy of `dev` for kernels that take it by pointer
   std::vector<SearchArgs> h_sargs;   // one argument block per triangle group
   SearchArgs* d_sargs = nullptr;
   double* d_tabs = nullptr;  // utab then vtab
   size_t cap_tabs = 0;
+  std::array<double, 18> tabs_key{};  // what the tables were computed for
+  bool tabs_valid = false;
+  std::vector<SearchArgs> sargs_uploaded;  // what d_sargs holds
   int2* d_blocks = nullptr;
   size_t cap_blocks = 0;
   std::vector<int2> h_blocks;          // host copy of the block list last uploaded
   std::array<int, 9> blocks_key{};     // frame geometry + tile selection it was built for
   bool blocks_valid = false;
   DevCounters* d_cnt = nullptr;
+  int n_plain_shadeable = 0;  // spheres and lights in the object list (hits on them go through the shade queue)
   int exact_grid = 2048;  // workgroups of the grid-stride k_search_exact: eight per compute unit
   // one frame may be in flight between rtmi_render_begin and rtmi_render_end
   bool pending = false;
@@ -1689,7 +1695,7 @@ extern "C" void rtmi_scene_destroy(rtmi_scene* sc) {
   (void)hipFree(sc->d_gsph); (void)hipFree(sc->d_gst2); (void)hipFree(sc->d_run_start);
   (void)hipFree(sc->d_hit_id); (void)hipFree(sc->d_tri_hit); (void)hipFree(sc->d_q_child);
   (void)hipFree(sc->d_q_shade); (void)hipFree(sc->d_q_top); (void)hipFree(sc->d_rgb);
-  (void)hipFree(sc->d_dirs); (void)hipFree(sc->d_tval); (void)hipFree(sc->d_best_pos); (void)hipFree(sc->d_cand); (void)hipFree(sc->d_fc); (void)hipFree(sc->d_tabs); (void)hipFree(sc->d_sargs); (void)hipFree(sc->d_scdev);
+  (void)hipFree(sc->d_dirs); (void)hipFree(sc->d_tval); (void)hipFree(sc->d_best_pos); (void)hipFree(sc->d_cand); (void)hipFree(sc->d_tabs); (void)hipFree(sc->d_sargs);
   (void)hipFree(sc->d_blocks); (void)hipFree(sc->d_cnt);
   if (sc->h_cnt) (void)hipHostFree(sc->h_cnt);
   for (auto& pr : sc->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -1759,6 +1765,7 @@ static int32_t scene_create_impl(const rtmi_scene_desc* desc, int32_t device, rt
       }
     } else {
       ++n_sphere_like;
+      if (ob.kind != RTMI_BOUNDING_SPHERE) ++sc->n_plain_shadeable;
       if (ob.kind == RTMI_BOUNDING_SPHERE) {
         TriGroup g;
         g.object = (int)k;
@@ -1825,7 +1832,6 @@ static int32_t scene_create_impl(const rtmi_scene_desc* desc, int32_t device, rt
   }
   HIP_TRY(hipMalloc(&sc->d_cnt, sizeof(DevCounters)));
   HIP_TRY(hipHostMalloc((void**)&sc->h_cnt, sizeof(DevCounters), hipHostMallocDefault));
-  HIP_TRY(hipMalloc(&sc->d_fc, sizeof(FrameConst)));
   sc->h_sargs.resize(sc->groups.size());
   HIP_TRY(hipMalloc(&sc->d_sargs, sizeof(SearchArgs) * sc->groups.size()));
   HIP_TRY(hipStreamSynchronize(sc->stream));
@@ -1844,8 +1850,6 @@ static int32_t scene_create_impl(const rtmi_scene_desc* desc, int32_t device, rt
   sc->dev.top_group = sc->groups[0].d_group;
   sc->dev.run_start = sc->d_run_start;
   for (int a = 0; a < 3; ++a) sc->dev.c0[a] = c0[a];
-  HIP_TRY(hipMalloc(&sc->d_scdev, sizeof(SceneDev)));
-  HIP_TRY(hipMemcpy(sc->d_scdev, &sc->dev, sizeof(SceneDev), hipMemcpyHostToDevice));
   return RTMI_OK;
 }
 
@@ -1993,6 +1997,7 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
       sc->cap_tabs = 0;
       HIP_TRY(hipMalloc(&sc->d_tabs, sizeof(double) * need));
       sc->cap_tabs = need;
+      sc->tabs_valid = false;
     }
     fc.utab = sc->d_tabs;
     fc.vtab = sc->d_tabs + (size_t)p->width * n1 * 3;
@@ -2040,8 +2045,6 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
   hipStream_t st = sc->stream;
   HIP_TRY(hipEventRecord(sc->ev_a, st));
   HIP_TRY(hipMemsetAsync(sc->d_cnt, 0, sizeof(DevCounters), st));
-  sc->h_fc = fc;  // lives in the scene object: the async copy may read it after this statement
-  HIP_TRY(hipMemcpyAsync(sc->d_fc, &sc->h_fc, sizeof(FrameConst), hipMemcpyHostToDevice, st));
   if (!blocks_cached || !sc->blocks_valid) {
     if (!blocks.empty())
       HIP_TRY(hipMemcpyAsync(sc->d_blocks, blocks.data(), sizeof(int2) * blocks.size(), hipMemcpyHostToDevice, st));
@@ -2049,14 +2052,29 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
     sc->blocks_valid = true;
   }
 
+  // Per-frame preparation that depends only on the camera and the frame geometry is kept from the
+  // previous frame when those are unchanged (a viewer that re-renders with other lights, or a
+  // benchmark loop): the sample tables, and each group's search operands for this camera position.
   {
-    int ntab = (p->width + p->height) * n1;
-    hipLaunchKernelGGL(k_frame_tables, dim3((ntab + 255) / 256), dim3(256), 0, st, fc, sc->d_tabs,
-                       sc->d_tabs + (size_t)p->width * n1 * 3);
+    std::array<double, 18> key = {fc.ul[0], fc.ul[1], fc.ul[2], fc.u[0], fc.u[1], fc.u[2], fc.v[0], fc.v[1], fc.v[2],
+                                  fc.ppw_h, fc.ppw_v, fc.sub, (double)fc.W, (double)fc.H, (double)fc.n1,
+                                  (double)(uintptr_t)fc.utab, 0.0, 0.0};
+    if (!sc->tabs_valid || memcmp(key.data(), sc->tabs_key.data(), sizeof(double) * key.size()) != 0) {
+      int ntab = (p->width + p->height) * n1;
+      hipLaunchKernelGGL(k_frame_tables, dim3((ntab + 255) / 256), dim3(256), 0, st, fc, sc->d_tabs,
+                         sc->d_tabs + (size_t)p->width * n1 * 3);
+      sc->tabs_key = key;
+      sc->tabs_valid = true;
+    }
   }
   d3 camera = rtx::ld3(cam->pos);
-  for (auto& g : sc->groups)
+  for (auto& g : sc->groups) {
+    const int want = use_tree ? 1 : 2;
+    if (g.packed_for == want && memcmp(g.packed_cam, cam->pos, sizeof(g.packed_cam)) == 0) continue;
     if ((rc = use_tree ? pack_group_tree(sc, g, camera) : pack_group(sc, g, camera))) return rc;
+    g.packed_for = want;
+    memcpy(g.packed_cam, cam->pos, sizeof(g.packed_cam));
+  }
 
   // argument blocks of the search launches (one per triangle group), uploaded once per frame
   for (size_t gi = 0; gi < sc->groups.size(); ++gi) {
@@ -2084,7 +2102,12 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
     a.cand_cap = (int)std::min<size_t>(sc->cap_samples, 0x7fffffff);
     a.tree = g.tree;
   }
-  HIP_TRY(hipMemcpyAsync(sc->d_sargs, sc->h_sargs.data(), sizeof(SearchArgs) * sc->groups.size(), hipMemcpyHostToDevice, st));
+  if (sc->sargs_uploaded.size() != sc->h_sargs.size() ||
+      memcmp(sc->sargs_uploaded.data(), sc->h_sargs.data(), sizeof(SearchArgs) * sc->h_sargs.size()) != 0) {
+    // staged through a copy that stays untouched until the next upload: the async copy reads it later
+    sc->sargs_uploaded = sc->h_sargs;
+    HIP_TRY(hipMemcpyAsync(sc->d_sargs, sc->sargs_uploaded.data(), sizeof(SearchArgs) * sc->groups.size(), hipMemcpyHostToDevice, st));
+  }
 
   ShadeConst shc;
   for (int a = 0; a < 3; ++a) { shc.cam[a] = fc.cam[a]; shc.ambient[a] = fc.ambient[a]; }
@@ -2110,7 +2133,7 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
     size_t nb = std::min(blocks_per_batch, blocks.size() - b0);
     int nsamples = (int)(nb * samples_per_block);
     const int2* d_blk = sc->d_blocks + b0;
-    HIP_TRY(hipMemsetAsync(&sc->d_cnt->q_child, 0, sizeof(int) * 3, st));
+    if (b0 > 0) HIP_TRY(hipMemsetAsync(&sc->d_cnt->q_child, 0, sizeof(int) * 3, st));  // the first batch starts from the cleared counters
     int grid = (nsamples + 255) / 256;
     hipLaunchKernelGGL(k_gen, dim3((nsamples + 256 * GEN_ITERS - 1) / (256 * GEN_ITERS)), dim3(256), 0, st, fc, sc->dev, d_blk, nsamples, sc->d_hit_id, sc->d_dirs, sc->d_q_child,
                        sc->d_q_shade, sc->d_q_top, sc->d_cnt);
@@ -2150,6 +2173,9 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
     }
     for (size_t gi = 1; gi < sc->groups.size(); ++gi)
       if ((rc = search_group(gi))) return rc;
+    // the shade queue stays empty when the cone tree shades every triangle hit itself and the scene
+    // lists nothing else that can be shaded (no sphere or light object, no top-level triangles)
+    if (!(use_tree && !has_top_runs && sc->n_plain_shadeable == 0))
     hipLaunchKernelGGL(has_top_runs ? k_shade<true> : k_shade<false>, dim3(std::min(grid, 4 * sc->exact_grid)), dim3(256), 0, st, shc, sc->dev, sc->d_dirs, sc->d_tval, sc->d_q_shade, &sc->d_cnt->q_shade,
                        sc->d_hit_id, sc->d_rgb, sc->d_cnt);
     int npix = (int)(nb * BLK_PIX);
