@@ -72,9 +72,18 @@ struct FrameConst {
   double ambient[3];
   int W, H, x0, y0, x1, y1;
   int spp, n1;  // samples per pixel = n1*n1 (WorldCoordinateSequence.swift:74-78)
+  int spp_shift, n1_shift;  // log2 of the two when they are powers of two, else -1
   float inv_spp;
   const double* utab;  // per sample column: (u * i) / pixelsPerWorldHorizontal
   const double* vtab;  // per sample row:    (v * j) / pixelsPerWorldVertical
+  // FP32 pre-test of k_gen: the same tables rounded to FP32, ul - cam, and one cone per sphere-like
+  // object (unit vector towards its centre, and the squared cosine a direction must reach to
+  // come anywhere near it); n_genf == 0 switches the pre-test off
+  const float* utab_f;
+  const float* vtab_f;
+  const float4* genf;
+  float base_f[3];
+  int n_genf;
   int tile_size, tiles_x, tile_rank, tile_world;
 };
 
@@ -129,26 +138,32 @@ __device__ inline bool pixel_coords(const FrameConst& fc, const int2* __restrict
   return true;
 }
 
-// Sample index within a batch -> pixel and sub-sample.  s = ((b*spp + k) << 6) + pix: the 64
-// lanes of a wave are the 64 pixels of one 8x8 block at the same sub-sample, so per-sample
-// arrays are read and written coalesced by k_gen, k_search_primary and k_resolve alike.
-__device__ inline bool sample_coords(const FrameConst& fc, const int2* __restrict__ blocks, int s,
-                                     int* x, int* y, int* k) {
-  int pix = s & (BLK_PIX - 1);
-  int t = s >> 6;
-  int b = (int)((float)t * fc.inv_spp);  // t / spp for t < 2^22, corrected below
-  int rem = t - b * fc.spp;
-  if (rem < 0) { --b; rem += fc.spp; }
-  if (rem >= fc.spp) { ++b; rem -= fc.spp; }
-  *k = rem;
-  return pixel_coords(fc, blocks, b, pix, x, y);
+// Sample index within a batch: s = ((b*spp + k) << 6) + pix.  The 64 lanes of a wave are the 64
+// pixels of one 8x8 block at the same sub-sample k, so per-sample arrays are read and written
+// coalesced by k_gen, the searches and k_resolve alike, and everything derived from t = s >> 6
+// (block, sub-sample, its column and row offsets) is wave-uniform scalar arithmetic.
+__device__ inline void group_coords(const FrameConst& fc, int t, int* b_out, int* kx_out, int* ky_out) {
+  int b, k;
+  if (fc.spp_shift >= 0) {  // 1, 4, 16 ... samples per pixel
+    b = t >> fc.spp_shift;
+    k = t & (fc.spp - 1);
+  } else {
+    b = (int)((float)t * fc.inv_spp);  // t / spp for t < 2^22, corrected below
+    k = t - b * fc.spp;
+    if (k < 0) { --b; k += fc.spp; }
+    if (k >= fc.spp) { ++b; k -= fc.spp; }
+  }
+  int kx;
+  if (fc.n1_shift >= 0) kx = k >> fc.n1_shift; else kx = k / fc.n1;
+  *b_out = b;
+  *kx_out = kx;               // x outer, y inner (WorldCoordinateSequence.swift:74-78)
+  *ky_out = k - kx * fc.n1;
 }
 
-// Primary ray direction of sample k of pixel (x, y): WorldCoordinateSequence.swift:62-78 and
-// RayTracingFunctions.swift:73.  The two quotients of pixelToWorldCoordinate depend only on the
-// sample's column and row; k_frame_tables evaluates them once per frame.
-__device__ inline d3 sample_dir(const FrameConst& fc, int x, int y, int k) {
-  int kx = k / fc.n1, ky = k - kx * fc.n1;  // x outer, y inner
+// Primary ray direction of sub-sample (kx, ky) of pixel (x, y): WorldCoordinateSequence.swift:62-78
+// and RayTracingFunctions.swift:73.  The two quotients of pixelToWorldCoordinate depend only on
+// the sample's column and row; k_frame_tables evaluates them once per frame.
+__device__ inline d3 sample_dir(const FrameConst& fc, int x, int y, int kx, int ky) {
   const double* uc = fc.utab + (size_t)(x * fc.n1 + kx) * 3;
   const double* vc = fc.vtab + (size_t)(y * fc.n1 + ky) * 3;
   d3 p = rtx::sub(rtx::add(rtx::ld3(fc.ul), rtx::ld3(uc)), rtx::ld3(vc));  // ul + uComponent - vComponent
@@ -157,7 +172,7 @@ __device__ inline d3 sample_dir(const FrameConst& fc, int x, int y, int k) {
 
 // uComponent = (u * i) / pixelsPerWorldHorizontal for every sample column i = x + kx*sub, and
 // vComponent = (v * j) / pixelsPerWorldVertical for every sample row (WCS:63-64, :74-75).
-__global__ void k_frame_tables(FrameConst fc, double* utab, double* vtab) {
+__global__ void k_frame_tables(FrameConst fc, double* utab, double* vtab, float* utab_f, float* vtab_f) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int nu = fc.W * fc.n1, nv = fc.H * fc.n1;
   if (i < nu) {
@@ -165,12 +180,14 @@ __global__ void k_frame_tables(FrameConst fc, double* utab, double* vtab) {
     double c = fma((double)kx, fc.sub, (double)x);  // stride(from:to:by:) = start.addingProduct(k, by)
     d3 r = rtx::divs(rtx::muls(rtx::ld3(fc.u), c), fc.ppw_h);
     utab[(size_t)i * 3 + 0] = r.x; utab[(size_t)i * 3 + 1] = r.y; utab[(size_t)i * 3 + 2] = r.z;
+    utab_f[(size_t)i * 3 + 0] = (float)r.x; utab_f[(size_t)i * 3 + 1] = (float)r.y; utab_f[(size_t)i * 3 + 2] = (float)r.z;
   } else if (i < nu + nv) {
     int j = i - nu;
     int y = j / fc.n1, ky = j - y * fc.n1;
     double c = fma((double)ky, fc.sub, (double)y);
     d3 r = rtx::divs(rtx::muls(rtx::ld3(fc.v), c), fc.ppw_v);
     vtab[(size_t)j * 3 + 0] = r.x; vtab[(size_t)j * 3 + 1] = r.y; vtab[(size_t)j * 3 + 2] = r.z;
+    vtab_f[(size_t)j * 3 + 0] = (float)r.x; vtab_f[(size_t)j * 3 + 1] = (float)r.y; vtab_f[(size_t)j * 3 + 2] = (float)r.z;
   }
 }
 
@@ -595,15 +612,37 @@ k_gen(FrameConst fc, SceneDev sc, const int2* __restrict__ blocks, int nsamples,
   if (threadIdx.x < 3) ln[threadIdx.x] = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const bool has_top = sc.n_top_tris > 0;
   for (int it = 0; it < GEN_ITERS; ++it) {
-    int s = (blockIdx.x * GEN_ITERS + it) * 256 + threadIdx.x;
-    int x, y, k;
-    bool live = s < nsamples && sample_coords(fc, blocks, s, &x, &y, &k);
+    const int t = (blockIdx.x * GEN_ITERS + it) * 4 + wv;  // wave-uniform: the 64-sample group of this wave
+    const int s = (t << 6) + lane;
+    int x = 0, y = 0, kx = 0, ky = 0;
+    bool live = false;
+    if ((t << 6) < nsamples) {  // nsamples is a multiple of 64
+      int b;
+      group_coords(fc, t, &b, &kx, &ky);
+      live = pixel_coords(fc, blocks, b, lane, &x, &y);
+    }
     int id = -1;
     bool to_child = false, to_shade = false;
+    if (live && fc.n_genf > 0) {
+      // FP32 pre-test: a sample whose direction stays clear of every object's cone hits nothing,
+      // and none of the FP64 work below is needed for it (hit_id = -1, no direction stored)
+      const float* uc = fc.utab_f + (size_t)(x * fc.n1 + kx) * 3;
+      const float* vc = fc.vtab_f + (size_t)(y * fc.n1 + ky) * 3;
+      const float fx = fc.base_f[0] + uc[0] - vc[0], fy = fc.base_f[1] + uc[1] - vc[1], fz = fc.base_f[2] + uc[2] - vc[2];
+      const float dd = fx * fx + fy * fy + fz * fz;
+      bool maybe = false;
+      for (int o = 0; o < fc.n_genf && !maybe; ++o) {
+        const float4 gf = fc.genf[o];
+        const float qd = gf.x * fx + gf.y * fy + gf.z * fz;
+        maybe = gf.w <= 0.0f || (qd > 0.0f && !(qd * qd < gf.w * dd));
+      }
+      live = maybe;
+    }
     if (live) {
-      d3 d = sample_dir(fc, x, y, k);
+      d3 d = sample_dir(fc, x, y, kx, ky);
       int obj = first_sphere_like(sc, rtx::ld3(fc.cam), d);
       if (obj >= 0) {
         id = -2 - obj;
@@ -1536,6 +1575,9 @@ struct rtmi_scene {
   std::array<double, 18> tabs_key{};  // what the tables were computed for
   bool tabs_valid = false;
   std::vector<SearchArgs> sargs_uploaded;  // what d_sargs holds
+  float4* d_genf = nullptr;                // k_gen pre-test operands, one per sphere-like object
+  std::vector<float4> genf_uploaded;
+  std::vector<rtmi_light> h_lights;
   int2* d_blocks = nullptr;
   size_t cap_blocks = 0;
   std::vector<int2> h_blocks;          // host copy of the block list last uploaded
@@ -1695,7 +1737,7 @@ extern "C" void rtmi_scene_destroy(rtmi_scene* sc) {
   (void)hipFree(sc->d_gsph); (void)hipFree(sc->d_gst2); (void)hipFree(sc->d_run_start);
   (void)hipFree(sc->d_hit_id); (void)hipFree(sc->d_tri_hit); (void)hipFree(sc->d_q_child);
   (void)hipFree(sc->d_q_shade); (void)hipFree(sc->d_q_top); (void)hipFree(sc->d_rgb);
-  (void)hipFree(sc->d_dirs); (void)hipFree(sc->d_tval); (void)hipFree(sc->d_best_pos); (void)hipFree(sc->d_cand); (void)hipFree(sc->d_tabs); (void)hipFree(sc->d_sargs);
+  (void)hipFree(sc->d_dirs); (void)hipFree(sc->d_tval); (void)hipFree(sc->d_best_pos); (void)hipFree(sc->d_cand); (void)hipFree(sc->d_tabs); (void)hipFree(sc->d_sargs); (void)hipFree(sc->d_genf);
   (void)hipFree(sc->d_blocks); (void)hipFree(sc->d_cnt);
   if (sc->h_cnt) (void)hipHostFree(sc->h_cnt);
   for (auto& pr : sc->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -1730,6 +1772,7 @@ static int32_t scene_create_impl(const rtmi_scene_desc* desc, int32_t device, rt
   HIP_TRY(hipEventCreate(&sc->ev_d));
 
   sc->objects.assign(desc->objects, desc->objects + desc->n_objects);
+  sc->h_lights.assign(desc->lights, desc->lights + desc->n_lights);
   sc->n_lights = desc->n_lights;
   sc->n_materials = desc->n_materials;
   sc->n_tris = desc->n_triangles;
@@ -1831,6 +1874,7 @@ static int32_t scene_create_impl(const rtmi_scene_desc* desc, int32_t device, rt
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipMalloc(&sc->d_cnt, sizeof(DevCounters)));
+  HIP_TRY(hipMalloc(&sc->d_genf, sizeof(float4) * std::max(1, n_sphere_like)));
   HIP_TRY(hipHostMalloc((void**)&sc->h_cnt, sizeof(DevCounters), hipHostMallocDefault));
   sc->h_sargs.resize(sc->groups.size());
   HIP_TRY(hipMalloc(&sc->d_sargs, sizeof(SearchArgs) * sc->groups.size()));
@@ -1984,6 +2028,11 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
   fc.W = p->width; fc.H = p->height;
   fc.x0 = x0; fc.y0 = y0; fc.x1 = x1; fc.y1 = y1;
   fc.spp = spp; fc.n1 = n1;
+  fc.spp_shift = fc.n1_shift = -1;
+  for (int sh = 0; sh < 16; ++sh) {
+    if ((1 << sh) == spp) fc.spp_shift = sh;
+    if ((1 << sh) == n1) fc.n1_shift = sh;
+  }
   fc.tile_size = p->tile_size;
   fc.tiles_x = p->tile_size > 0 ? (p->width - 1 + p->tile_size - 1) / p->tile_size : 1;
   fc.tile_rank = p->tile_rank;
@@ -1995,12 +2044,14 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
       (void)hipFree(sc->d_tabs);
       sc->d_tabs = nullptr;
       sc->cap_tabs = 0;
-      HIP_TRY(hipMalloc(&sc->d_tabs, sizeof(double) * need));
+      HIP_TRY(hipMalloc(&sc->d_tabs, (sizeof(double) + sizeof(float)) * need));  // FP64 tables, then their FP32 copies
       sc->cap_tabs = need;
       sc->tabs_valid = false;
     }
     fc.utab = sc->d_tabs;
     fc.vtab = sc->d_tabs + (size_t)p->width * n1 * 3;
+    fc.utab_f = reinterpret_cast<const float*>(sc->d_tabs + sc->cap_tabs);
+    fc.vtab_f = fc.utab_f + (size_t)p->width * n1 * 3;
   }
 
   // 8x8 pixel blocks that contain at least one pixel to render.  The list depends only on the
@@ -2036,6 +2087,12 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
   } else {
     live_samples = (int64_t)(x1 - x0) * (y1 - y0) * spp;
   }
+  // With tiles that are whole multiples of the 8x8 blocks the block list already holds exactly the
+  // owned pixels, and the kernels need no per-pixel ownership test (two integer divisions per pixel).
+  if (fc.tile_world > 1 && fc.tile_size % BLK == 0) {
+    fc.tile_world = 1;
+    fc.tile_size = 0;
+  }
   const size_t samples_per_block = (size_t)BLK_PIX * spp;
   const size_t blocks_per_batch = std::max<size_t>(1, MAX_BATCH_SAMPLES / samples_per_block);
   const size_t max_batch_blocks = std::min(blocks_per_batch, std::max<size_t>(blocks.size(), 1));
@@ -2045,6 +2102,46 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
   hipStream_t st = sc->stream;
   HIP_TRY(hipEventRecord(sc->ev_a, st));
   HIP_TRY(hipMemsetAsync(sc->d_cnt, 0, sizeof(DevCounters), st));
+
+  // FP32 pre-test of k_gen (scenes without top-level triangle runs: there every sample goes on to
+  // the triangle search anyway).  d' = (ul - cam) + uComponent - vComponent in FP32 differs from
+  // the FP64 direction by at most rel = sqrt(3)*8*2^-24*B/dmin in relative terms (B bounds the
+  // component magnitudes, dmin is the distance from the camera to the image plane), its squared
+  // cosine to a unit vector by a few times that; `margin` is far above it.  An object is cleared
+  // for a sample only if cos^2 < 1 - (r/|m|)^2 - margin, i.e. the direction misses the sphere
+  // around the object by a visible angle; everything closer is decided in FP64 as before.
+  fc.n_genf = 0;
+  fc.genf = sc->d_genf;
+  if (sc->groups[0].n == 0 && sc->dev.n_sphere_like > 0) {
+    const double base[3] = {fc.ul[0] - fc.cam[0], fc.ul[1] - fc.cam[1], fc.ul[2] - fc.cam[2]};
+    const double dlen = sqrt(cam->dir[0] * cam->dir[0] + cam->dir[1] * cam->dir[1] + cam->dir[2] * cam->dir[2]);
+    const double dmin = fabs(cam->focal_length) * dlen;
+    const double B = std::max(fabs(base[0]), std::max(fabs(base[1]), fabs(base[2]))) + 20.0;
+    const double rel = 1.7320508 * 8.0 * 5.9604644775390625e-08 * B / dmin;
+    const double margin = 8.0 * rel + 1.0e-5;
+    if (std::isfinite(margin) && margin < 0.05) {
+      std::vector<float4> gf;
+      for (const rtmi_object& ob : sc->objects) {
+        if (ob.kind == RTMI_TRIANGLES) continue;
+        const double* c = ob.kind == RTMI_LIGHT ? sc->h_lights[(size_t)ob.first].loc : ob.center;
+        const double r = ob.kind == RTMI_LIGHT ? 0.0 : fabs(ob.radius);
+        const double m[3] = {c[0] - fc.cam[0], c[1] - fc.cam[1], c[2] - fc.cam[2]};
+        const double ml = sqrt(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]);
+        float4 e = make_float4(0.f, 0.f, 0.f, -1.f);  // w <= 0: never cleared
+        if (std::isfinite(ml) && ml > r * 1.001 && ml > 0) {
+          const double c2 = 1.0 - (r / ml) * (r / ml) - margin;
+          if (c2 > 1.0e-3) e = make_float4((float)(m[0] / ml), (float)(m[1] / ml), (float)(m[2] / ml), (float)(c2 * (1.0 - 1.0e-6)));
+        }
+        gf.push_back(e);
+      }
+      if (gf.size() != sc->genf_uploaded.size() || memcmp(gf.data(), sc->genf_uploaded.data(), sizeof(float4) * gf.size()) != 0) {
+        sc->genf_uploaded = gf;  // stays untouched until the next upload: the async copy reads it later
+        HIP_TRY(hipMemcpyAsync(sc->d_genf, sc->genf_uploaded.data(), sizeof(float4) * gf.size(), hipMemcpyHostToDevice, st));
+      }
+      for (int a = 0; a < 3; ++a) fc.base_f[a] = (float)base[a];
+      fc.n_genf = (int)gf.size();
+    }
+  }
   if (!blocks_cached || !sc->blocks_valid) {
     if (!blocks.empty())
       HIP_TRY(hipMemcpyAsync(sc->d_blocks, blocks.data(), sizeof(int2) * blocks.size(), hipMemcpyHostToDevice, st));
@@ -2062,7 +2159,7 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
     if (!sc->tabs_valid || memcmp(key.data(), sc->tabs_key.data(), sizeof(double) * key.size()) != 0) {
       int ntab = (p->width + p->height) * n1;
       hipLaunchKernelGGL(k_frame_tables, dim3((ntab + 255) / 256), dim3(256), 0, st, fc, sc->d_tabs,
-                         sc->d_tabs + (size_t)p->width * n1 * 3);
+                         sc->d_tabs + (size_t)p->width * n1 * 3, const_cast<float*>(fc.utab_f), const_cast<float*>(fc.vtab_f));
       sc->tabs_key = key;
       sc->tabs_valid = true;
     }
