@@ -1070,60 +1070,56 @@ k_search_tree(const SearchArgs* __restrict__ ap, const f2* __restrict__ rec, con
   auto level_off = [&](int lvl) {
     return lvl == 1 ? o1 : lvl == 2 ? o2 : lvl == 3 ? o3 : lvl == 4 ? o4 : lvl == 5 ? o5 : lvl == 6 ? o6 : o7;
   };
-  // Level-0 record `ri`: the triangle cones of slots 8*ri..8*ri+7 against every ray of the lane,
-  // then, triangle by triangle, the edge test for the rays that passed; what remains is a candidate.
-  typedef typename std::conditional<(R > 4), unsigned long long, unsigned int>::type bits_t;
+  // Level-0 record `ri`: the triangle cones of slots 8*ri..8*ri+7 against every ray of the lane.
+  // A triangle that no ray of the wave passes costs three maxima and a vote; for the others the
+  // edge test follows at once, and what remains is a candidate.
   auto leaf = [&](int ri) {
     ++n_leaf_rec;
     const f2* rp = rec + (size_t)(o0 + ri) * (REC_DWORDS / 2);
-    bits_t bits = 0;  // bit j*R + r: ray r of this lane passes the cone of the record's triangle j
-    {
-      f2 cur[12];
+    f2 cur[12];
 #pragma unroll
-      for (int c = 0; c < 12; ++c) cur[c] = rp[c];
+    for (int c = 0; c < 12; ++c) cur[c] = rp[c];
+    const unsigned always = reinterpret_cast<const unsigned*>(rp)[REC_ALWAYS];  // wide triangles (NaN cones)
+    const float* edge = edge_all + (size_t)ri * (8 * EDGE_FLOATS);
 #pragma unroll
-      for (int pr = 0; pr < 4; ++pr) {
-        f2 q[R];
+    for (int pr = 0; pr < 4; ++pr) {
+      f2 q[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) { f2 X = {dx[r], dx[r]}; q[r] = cur[pr * 3 + 0] * X; }
+      for (int r = 0; r < R; ++r) { f2 X = {dx[r], dx[r]}; q[r] = cur[pr * 3 + 0] * X; }
 #pragma unroll
-        for (int r = 0; r < R; ++r) { f2 Y = {dy[r], dy[r]}; q[r] = __builtin_elementwise_fma(cur[pr * 3 + 1], Y, q[r]); }
+      for (int r = 0; r < R; ++r) { f2 Y = {dy[r], dy[r]}; q[r] = __builtin_elementwise_fma(cur[pr * 3 + 1], Y, q[r]); }
 #pragma unroll
-        for (int r = 0; r < R; ++r) { f2 Z = {dz[r], dz[r]}; q[r] = __builtin_elementwise_fma(cur[pr * 3 + 2], Z, q[r]); }
+      for (int r = 0; r < R; ++r) { f2 Z = {dz[r], dz[r]}; q[r] = __builtin_elementwise_fma(cur[pr * 3 + 2], Z, q[r]); }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int jj = pr * 2 + h;
+        float mq = h ? q[0].y : q[0].x;  // fmaxf drops the NaN of absent rays
+#pragma unroll
+        for (int r = 1; r < R; ++r) mq = __builtin_fmaxf(mq, h ? q[r].y : q[r].x);
+        if (!__any(mq >= 1.0f) && !((always >> jj) & 1u)) continue;
+        const float* m = edge + jj * EDGE_FLOATS;
+        const float m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3], m4 = m[4], m5 = m[5], m6 = m[6], m7 = m[7], m8 = m[8];
+        const int g = ri * 8 + jj;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-          // !(q < 1) also lets a NaN cone (wide triangle) through; absent rays have NaN directions
-          if (!(q[r].x < 1.0f) && sid[r] >= 0) bits |= (bits_t)1 << ((pr * 2) * R + r);
-          if (!(q[r].y < 1.0f) && sid[r] >= 0) bits |= (bits_t)1 << ((pr * 2 + 1) * R + r);
+          const float qv = h ? q[r].y : q[r].x;
+          float s0 = __builtin_fmaf(m2, dz[r], __builtin_fmaf(m1, dy[r], m0 * dx[r]));
+          float s1 = __builtin_fmaf(m5, dz[r], __builtin_fmaf(m4, dy[r], m3 * dx[r]));
+          float s2 = __builtin_fmaf(m8, dz[r], __builtin_fmaf(m7, dy[r], m6 * dx[r]));
+          float e = __builtin_fmaxf(__builtin_fmaxf(s0, s1), s2);
+          // !(q < 1) also lets a NaN cone (wide triangle) through; absent rays are excluded by sid
+          const bool pass = !(qv < 1.0f) && sid[r] >= 0 && e <= 1.0f;
+          const unsigned long long bm = __ballot(pass);
+          if (bm == 0) continue;
+          const int n = __popcll(bm);
+          if (fill + n > CAND_STAGE) {
+            cand_flush(ap, stage, fill, lane, wave & (NSLOT - 1), parity);
+            fill = 0;
+            __builtin_amdgcn_wave_barrier();
+          }
+          if (pass) stage[fill + __popcll(bm & ((1ull << lane) - 1ull))] = make_int2(sid[r], g);
+          fill += n;
         }
-      }
-    }
-    if (!__any(bits != 0)) return;
-    const float* edge = edge_all + (size_t)ri * (8 * EDGE_FLOATS);
-#pragma nounroll
-    for (int j = 0; j < 8; ++j) {
-      const unsigned mine = (unsigned)(bits >> (j * R)) & ((1u << R) - 1u);
-      if (!__any(mine != 0)) continue;
-      const float* m = edge + j * EDGE_FLOATS;
-      const float m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3], m4 = m[4], m5 = m[5], m6 = m[6], m7 = m[7], m8 = m[8];
-      const int g = ri * 8 + j;
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        float s0 = __builtin_fmaf(m2, dz[r], __builtin_fmaf(m1, dy[r], m0 * dx[r]));
-        float s1 = __builtin_fmaf(m5, dz[r], __builtin_fmaf(m4, dy[r], m3 * dx[r]));
-        float s2 = __builtin_fmaf(m8, dz[r], __builtin_fmaf(m7, dy[r], m6 * dx[r]));
-        float e = __builtin_fmaxf(__builtin_fmaxf(s0, s1), s2);
-        const bool pass = ((mine >> r) & 1u) && e <= 1.0f;
-        const unsigned long long bm = __ballot(pass);
-        if (bm == 0) continue;
-        const int n = __popcll(bm);
-        if (fill + n > CAND_STAGE) {
-          cand_flush(ap, stage, fill, lane, wave & (NSLOT - 1), parity);
-          fill = 0;
-          __builtin_amdgcn_wave_barrier();
-        }
-        if (pass) stage[fill + __popcll(bm & ((1ull << lane) - 1ull))] = make_int2(sid[r], g);
-        fill += n;
       }
     }
   };
@@ -1219,12 +1215,8 @@ k_search_finish(const SearchArgs* __restrict__ ap, int parity) {
   const int pos = ap->best_pos[s];
   if (pos != 0x7fffffff) {
     ti = ap->group[pos];
-    const rtmi_triangle& tr = ap->tris[ti];
     const double* dp = ap->dirs + (size_t)s * 3;
-    d3 P;
-    double tv = 0.0;
-    rtx::tri_hit(rtx::ld3(tr.v[0]), rtx::ld3(tr.v[1]), rtx::ld3(tr.v[2]), ap->planes[ti], rtx::ld3(ap->cam),
-                 rtx::mk(dp[0], dp[1], dp[2]), &tv, &P);
+    const double tv = rtx::tri_t(ap->planes[ti], rtx::ld3(ap->cam), rtx::mk(dp[0], dp[1], dp[2]));
     ap->tval[s] = tv;  // the hit point is origin + t*direction; shading rebuilds it
   }
   ap->tri_hit[q] = ti;
@@ -1444,7 +1436,7 @@ k_shade(ShadeConst fc, SceneDev sc, const double* __restrict__ dirs,
 // (grid-stride over the NSLOT lists, like k_search_exact).  The candidate whose list position is
 // the ray's lowest hit -- k_search_exact has settled that -- is the ray's intersection: its
 // triangle index goes to hit_id and the sample is shaded here, without a detour through the
-// shade queue.  t comes from the same FP64 evaluation once more (it is deterministic).  Samples
+// shade queue.  t is evaluated once more (the same two operations, the same value).  Samples
 // without a hit keep the bounding object's marker in hit_id; k_resolve reads that as a miss.
 template <bool HAS_TOP>
 __global__ void __launch_bounds__(256, HAS_TOP ? 2 : 4)
@@ -1464,10 +1456,7 @@ k_shade_candidates(ShadeConst fc, SceneDev sc, const SearchArgs* __restrict__ ap
       const int ti = ap->tree.slot_tri[g];
       const double* dp = dirs + (size_t)s * 3;
       const d3 d = rtx::mk(dp[0], dp[1], dp[2]);
-      const rtmi_triangle& tr = sc.tris[ti];
-      d3 P;
-      double tv = 0.0;
-      rtx::tri_hit(rtx::ld3(tr.v[0]), rtx::ld3(tr.v[1]), rtx::ld3(tr.v[2]), sc.planes[ti], rtx::ld3(fc.cam), d, &tv, &P);
+      const double tv = rtx::tri_t(sc.planes[ti], rtx::ld3(fc.cam), d);  // k_search_exact accepted this pair
       ap->hit_id[s] = ti;
       shade_sample<HAS_TOP>(fc, sc, s, d, ti, tv, rgb, &tl);
     }

@@ -101,6 +101,14 @@ RT_HD bool tri_hit(d3 v0, d3 v1, d3 v2, const TriPlane& pl, d3 origin, d3 direct
   return false;
 }
 
+// The intersection parameter alone (REN:144-152), for a pair that tri_hit has already accepted:
+// the same two operations, hence the same value.
+RT_HD double tri_t(const TriPlane& pl, d3 origin, d3 direction) {
+  d3 normal = mk(pl.nx, pl.ny, pl.nz);
+  double nddot = dp(normal, neg(direction));
+  return (pl.c - dp(normal, origin)) / -nddot;
+}
+
 // Sphere.intersections (REN:248-282) reduced to its first element: the smallest root that
 // passes the >= 1e-7 filter, with its point and the un-normalised outward vector p - location
 // (REN:276 normalises it; callers that never read the normal skip that).
