@@ -23,6 +23,18 @@ if ROOT not in sys.path:
 
 FLOPS_PER_TEST = 69            # reference triangle test with ray-independent terms hoisted
 PEAK_FP32_TFLOPS = 157.3       # MI355X vector FP32 (256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz)
+PEAK_FP64_TFLOPS = 78.6        # MI355X vector FP64 (256 CU x 4 SIMD x 32 FLOP/clk x 2.4 GHz; v_fma_f64 measured at 73 TFLOP/s)
+
+
+def shade_flops_per_hit(n_lights, n_sphere_like):
+    """FP64 operations of calculateLighting (RayTracingFunctions.swift:182-271) for one triangle hit with a
+    material in a scene whose other objects are `n_sphere_like` material-less bounding spheres (form B);
+    +, -, *, /, sqrt and pow count 1 each, a normalize is 9 (dot 5, sqrt, 3 divisions):
+    hit point 6, surfaceToCamera 12, reflection direction 12, the reflection ray's sphere tests
+    22 each + 13 for the hit it finds, the unlit reflected hit's light loop 26 per light,
+    and per light of the primary hit 57 (direction 12, n.l 5, diffuse 9, reflection of the light 16,
+    r.v 5, pow 1, specular 9)."""
+    return 6 + 12 + 12 + 22 * n_sphere_like + 13 + 26 * n_lights + 57 * n_lights
 
 CONFIGS = {
     # name: (width, height, subdivision, mesh level, n_lights)
@@ -39,6 +51,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="C3", choices=sorted(CONFIGS))
     ap.add_argument("--form", default="B", choices=["B", "T"])
+    ap.add_argument("--search", default="tree", choices=["tree", "scan"],
+                    help="triangle search of the timed region: the cone tree (default) or the list scan")
+    ap.add_argument("--no-scan-leg", action="store_true",
+                    help="skip the extra list-scan frames that measure BASELINE's tests/s figure (1 GPU only)")
     ap.add_argument("--orbit", action="store_true", help="config 5: move the camera every step")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-threads", type=int, default=16)
@@ -97,7 +113,9 @@ def main():
     if world > 1:
         data = sharding.broadcast_scene(data, 0, device=comm_dev)  # RCCL byte broadcast, once
     scene = rt.Scene(data, device=local_rank)
-    params = scenes.make_params(W, H, sub)
+    from raytracer_amd import _abi
+    search = _abi.RTMI_SEARCH_CONE_TREE if args.search == "tree" else _abi.RTMI_SEARCH_LIST_SCAN
+    params = scenes.make_params(W, H, sub, search=search)
     my_params = sharding.tile_params(params, rank, world) if world > 1 else params
     composer = sharding.TileComposer(W, H, rank, world, comm_dev)
     staging = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev) if args.rehearse_gloo else None
@@ -109,7 +127,7 @@ def main():
         return scenes.make_camera(**scenes.MESH_CAMERA)
 
     totals = {"rays": 0, "refl": 0, "shadow": 0, "elided": 0, "tests": 0, "tests_primary": 0, "ms_primary": 0.0, "launches": 0, "ms_total": 0.0,
-              "exact": 0, "samples": 0}
+              "exact": 0, "samples": 0, "hits": 0, "ms_shade": 0.0, "node_tests": 0, "candidates": 0}
 
     def step(i, record):
         # Frames alternate between two buffers: the gather of frame i (enqueued, asynchronous) overlaps
@@ -137,6 +155,10 @@ def main():
             totals["ms_total"] += cnt["ms_total"]
             totals["launches"] += cnt["tri_search_launches"]
             totals["exact"] += cnt["tri_exact_tests"]
+            totals["hits"] += cnt["primary_hits"]
+            totals["ms_shade"] += cnt["ms_shade"]
+            totals["node_tests"] += cnt["node_tests"]
+            totals["candidates"] += cnt["tri_candidates"]
 
     pending_slot = [None]  # frame rendered but not yet gathered
 
@@ -182,12 +204,41 @@ def main():
     else:
         total_rays, total_tests, elapsed_max = agg[0].item(), agg[1].item(), elapsed
 
+    scan_leg = None
+    if rank == 0 and world == 1 and args.search == "tree" and not args.no_scan_leg:
+        scan_leg = list_scan_leg(scene, camera_for(args.warmup), params, composer.frames[0], min(3, max(1, args.steps)), args.config)
+
     if rank == 0:
         mrays = total_rays / elapsed_max / 1e6
         tests_per_s = total_tests / elapsed_max
         launches = max(totals["launches"], 1)
-        avg_ms = totals["ms_primary"] / launches
-        achieved = (totals["tests_primary"] / launches) * FLOPS_PER_TEST / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        if args.search == "scan":
+            avg_ms = totals["ms_primary"] / launches
+            roofline = scan_roofline(totals["tests_primary"] / launches, avg_ms, args.config)
+        else:
+            # the dominant kernel of the timed region is the shading of the decided hits (FP64)
+            flops_hit = shade_flops_per_hit(n_lights, 1 if args.form == "B" else 0)
+            ms_shade = totals["ms_shade"] / args.steps
+            hits = totals["hits"] / args.steps
+            achieved = hits * flops_hit / (ms_shade * 1e-3) / 1e12 if ms_shade > 0 else 0.0
+            roofline = {
+                "bound": "valu_fp64",
+                "kernel": "k_shade_candidates" if args.form == "B" else "k_shade",
+                "achieved": round(achieved, 3),
+                "peak": PEAK_FP64_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_FP64_TFLOPS, 4),
+                "traffic": traffic_from_profile(args.config, "k_shade_candidates"),
+                "traffic_unit": "bytes of HBM traffic per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes; profiles/)",
+                "flops_per_hit_algorithmic": flops_hit,
+                "hits_per_launch": hits,
+                "avg_launch_ms": round(ms_shade, 4),
+                "note": "achieved = shaded hits per launch x the FP64 operations of calculateLighting per hit (division, sqrt, "
+                        "pow counted as 1) / launch time (HIP events on the library's stream).  An IEEE FP64 division costs "
+                        "about 13 instructions on this ISA and a sqrt about 20, and the reference's arithmetic (3 divisions "
+                        "per normalize) is kept operation for operation, so the kernel executes several instructions "
+                        "per counted operation; see DESIGN.md for the instruction-level accounting.",
+            }
         out = {
             "metric": "Mrays/s + ray-tri tests/s (% FP32 peak), pig OBJ 4K 16spp, 1/2/4/8 GPU",
             "value": round(mrays, 3),
@@ -207,6 +258,8 @@ def main():
                             f"form {args.form} ({'bounded by Sphere(boundingObjects:)' if args.form == 'B' else 'top-level triangles'}), "
                             "list-order hit policy" + (", orbiting camera" if args.orbit else ""),
                 "mesh": mesh_note,
+                "search": "cone tree (per-frame cone hierarchy; every hit of a ray is found, the lowest list position wins)"
+                          if args.search == "tree" else "list scan (every front-facing triangle in list order until the ray's first hit)",
                 "tiles": "32x32 cyclic over ranks, own pixels gathered on rank 0" if world > 1 else "single GPU, whole frame",
             },
             "verified_against_single_gpu_frame": verified,
@@ -218,29 +271,21 @@ def main():
                                             "shadow rays start at hits on material-less objects and are not traced because "
                                             "their outcome cannot change the pixel"},
             "tests_per_s": tests_per_s,
+            "tests_note": "(ray, triangle) pairs actually evaluated by a kernel lane per second over the timed region; pairs "
+                          "skipped by the origin-side cull, the cone tree or a ray's early exit are not counted",
             "tests_per_s_frac_of_fp32_roofline": tests_per_s * FLOPS_PER_TEST / (PEAK_FP32_TFLOPS * 1e12 * world),
+            "search_rank0_per_step": {"ms_tri_search": round(totals["ms_primary"] / args.steps, 4),
+                                      "ms_shade": round(totals["ms_shade"] / args.steps, 4),
+                                      "tri_tests": totals["tests_primary"] // args.steps,
+                                      "node_tests": totals["node_tests"] // args.steps,
+                                      "candidates": totals["candidates"] // args.steps,
+                                      "fp64_decisions": totals["exact"] // args.steps,
+                                      "primary_hits": totals["hits"] // args.steps},
             "device_ms_per_step_rank0": round(totals["ms_total"] / args.steps, 4),
-            "roofline": {
-                "bound": "valu_fp32",
-                "kernel": "k_search_primary",
-                "achieved": round(achieved, 3),
-                "peak": PEAK_FP32_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
-                "traffic": traffic_from_profile(args.config),
-                "traffic_unit": "bytes of HBM traffic per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, "
-                                "separate passes; profiles/r01_pmc_search_kernel.json)",
-                "flops_per_test_algorithmic": FLOPS_PER_TEST,
-                "tests_per_launch": totals["tests_primary"] / launches,
-                "avg_launch_ms": round(avg_ms, 4),
-                "executed_fp32_flops_per_test": 7,
-                "note": "achieved = evaluated (ray, triangle) pairs per launch x 69 algorithmic flops / launch time "
-                        "(HIP events on the library's stream).  The kernel decides most pairs with a conservative "
-                        "3-FMA cone test (about 7 executed FP32 flops per pair incl. the max), the rest with a 9-FMA "
-                        "edge test and an FP64 reference-order test, so frac exceeds 1 by construction; the VALU "
-                        "is 88% busy during the launch (SQ_ACTIVE_INST_VALU, profiles/).",
-            },
+            "roofline": roofline,
         }
+        if scan_leg is not None:
+            out["list_scan"] = scan_leg
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(data, params, args.cpu_threads)
         print(json.dumps(out), flush=True)
@@ -250,15 +295,69 @@ def main():
         dist.destroy_process_group()
 
 
-def traffic_from_profile(config):
-    """HBM bytes per k_search_primary launch from the committed PMC profile of this configuration
+def traffic_from_profile(config, kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC profile of this configuration
     (bench.py itself cannot collect PMC counters); None if there is none for `config`."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_search_kernel.json")
+    name = {"k_search_primary": "r01_pmc_search_kernel.json", "k_shade_candidates": "r01_pmc_shade_kernel.json"}[kernel]
     try:
-        d = json.load(open(path))
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
     except OSError:
         return None
     return d.get("hbm_bytes_per_launch") if d.get("config") == config else None
+
+
+def scan_roofline(tests_per_launch, avg_ms, config):
+    """BASELINE's figure for the list-scan kernel: evaluated pairs x 69 algorithmic flops / launch time."""
+    achieved = tests_per_launch * FLOPS_PER_TEST / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+    return {
+        "bound": "valu_fp32",
+        "kernel": "k_search_primary",
+        "achieved": round(achieved, 3),
+        "peak": PEAK_FP32_TFLOPS,
+        "unit": "TFLOP/s",
+        "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
+        "traffic": traffic_from_profile(config, "k_search_primary"),
+        "traffic_unit": "bytes of HBM traffic per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, "
+                        "separate passes; profiles/r01_pmc_search_kernel.json)",
+        "flops_per_test_algorithmic": FLOPS_PER_TEST,
+        "tests_per_launch": tests_per_launch,
+        "avg_launch_ms": round(avg_ms, 4),
+        "executed_fp32_flops_per_test": 7,
+        "note": "achieved = evaluated (ray, triangle) pairs per launch x 69 algorithmic flops / launch time "
+                "(HIP events on the library's stream).  The kernel decides most pairs with a conservative "
+                "3-FMA cone test (about 7 executed FP32 flops per pair incl. the max), the rest with a 9-FMA "
+                "edge test and an FP64 reference-order test, so frac exceeds 1 by construction; the VALU "
+                "is 88% busy during the launch (SQ_ACTIVE_INST_VALU, profiles/).",
+    }
+
+
+def list_scan_leg(scene, cam, params, frame, steps, config):
+    """The same frame with RTMI_SEARCH_LIST_SCAN, after the timed region: the brute-force figure BASELINE's
+    metric names (ray-triangle tests/s against the FP32 peak) for the kernel that performs it."""
+    import copy
+    import torch
+    from raytracer_amd import _abi
+    p = copy.copy(params)
+    p.search = _abi.RTMI_SEARCH_LIST_SCAN
+    scene.render_device(cam, p, frame.data_ptr())  # warm-up: packs the list-scan operands
+    tests = ms = ms_total = rays = 0.0
+    launches = 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        c = scene.render_device(cam, p, frame.data_ptr())
+        tests += c["tri_tests_primary_kernel"]
+        ms += c["ms_primary_kernel"]
+        ms_total += c["ms_total"]
+        launches += c["tri_search_launches"]
+        rays += c["samples"] + c["rays_reflection"] + c["rays_shadow"]
+    dt = time.perf_counter() - t0
+    launches = max(launches, 1)
+    r = scan_roofline(tests / launches, ms / launches, config)
+    r.update({"steps": steps, "ms_per_step": round(dt / steps * 1e3, 4), "mrays_per_s": round(rays / dt / 1e6, 3),
+              "tests_per_s": tests / dt,
+              "tests_per_s_frac_of_fp32_roofline": tests / dt * FLOPS_PER_TEST / (PEAK_FP32_TFLOPS * 1e12)})
+    return r
 
 
 def scene_spp(sub):

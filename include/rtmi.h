@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RTMI_ABI_VERSION 1
+#define RTMI_ABI_VERSION 2
 
 typedef enum {
   RTMI_OK = 0,
@@ -148,10 +148,12 @@ typedef struct {
   int64_t tri_candidates;   /* cone tree only: pairs that passed the triangle cone and went
                                on to the edge test                                       */
   double ms_total;          /* device time of the whole call (HIP events)                */
-  double ms_tri_search;     /* device time of the triangle search launches only          */
+  double ms_tri_search;     /* device time of the triangle search launches only (cone tree: walk and
+                               FP64 decision; list scan: the scan kernel)                */
   int64_t tri_search_launches;
   int64_t tri_tests_primary_kernel; /* pairs evaluated by the common-origin kernel       */
   double ms_primary_kernel; /* its accumulated launch time                               */
+  double ms_shade;          /* device time of the shading launches                       */
 } rtmi_counters;
 
 typedef struct rtmi_scene rtmi_scene;

@@ -1578,10 +1578,11 @@ struct rtmi_scene {
   // one frame may be in flight between rtmi_render_begin and rtmi_render_end
   bool pending = false;
   DevCounters* h_cnt = nullptr;  // pinned host copy of the device counters
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;  // event pairs around search launches, reused
+  std::vector<std::array<hipEvent_t, 3>> ev_pool;  // per search launch: before, after the search, after its shading; reused
   size_t ev_used = 0;
   long long pend_launches = 0;
   int64_t pend_live_samples = 0;
+  bool pend_shade_timed = false;
   rtmi_camera pend_cam{};
   rtmi_params pend_params{};
   void* pend_rgba = nullptr;
@@ -1729,7 +1730,7 @@ extern "C" void rtmi_scene_destroy(rtmi_scene* sc) {
   (void)hipFree(sc->d_dirs); (void)hipFree(sc->d_tval); (void)hipFree(sc->d_best_pos); (void)hipFree(sc->d_cand); (void)hipFree(sc->d_tabs); (void)hipFree(sc->d_sargs); (void)hipFree(sc->d_genf);
   (void)hipFree(sc->d_blocks); (void)hipFree(sc->d_cnt);
   if (sc->h_cnt) (void)hipHostFree(sc->h_cnt);
-  for (auto& pr : sc->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  for (auto& tr : sc->ev_pool) for (hipEvent_t e : tr) (void)hipEventDestroy(e);
   if (sc->ev_a) (void)hipEventDestroy(sc->ev_a);
   if (sc->ev_b) (void)hipEventDestroy(sc->ev_b);
   if (sc->ev_c) (void)hipEventDestroy(sc->ev_c);
@@ -2202,18 +2203,17 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
   int launch_parity = 0;  // tree search launches of the frame alternate between two sets of list counters
   const bool has_top_runs = sc->groups[0].n > 0;
   sc->ev_used = 0;
-  auto next_events = [&](hipEvent_t* e0, hipEvent_t* e1) -> int32_t {
+  auto next_events = [&](hipEvent_t** ev) -> int32_t {
     if (sc->ev_used == sc->ev_pool.size()) {
-      hipEvent_t a, b;
-      HIP_TRY(hipEventCreate(&a));
-      HIP_TRY(hipEventCreate(&b));
-      sc->ev_pool.emplace_back(a, b);
+      std::array<hipEvent_t, 3> t{};
+      for (hipEvent_t& e : t) HIP_TRY(hipEventCreate(&e));
+      sc->ev_pool.push_back(t);
     }
-    *e0 = sc->ev_pool[sc->ev_used].first;
-    *e1 = sc->ev_pool[sc->ev_used].second;
+    *ev = sc->ev_pool[sc->ev_used].data();
     ++sc->ev_used;
     return RTMI_OK;
   };
+  bool shade_queue_launched = false;
 
   for (size_t b0 = 0; b0 < blocks.size(); b0 += blocks_per_batch) {
     size_t nb = std::min(blocks_per_batch, blocks.size() - b0);
@@ -2230,16 +2230,17 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
     // the triangle search of one group for the rays queued for it
     auto search_group = [&](size_t gi) -> int32_t {
       TriGroup& g = sc->groups[gi];
-      hipEvent_t e0, e1;
-      int32_t rc2 = next_events(&e0, &e1);
+      hipEvent_t* ev;
+      int32_t rc2 = next_events(&ev);
       if (rc2) return rc2;
-      HIP_TRY(hipEventRecord(e0, st));
+      HIP_TRY(hipEventRecord(ev[0], st));
       if (use_tree) {
         const int par = launch_parity;
         launch_parity ^= 1;
         hipLaunchKernelGGL(tree_kernel, dim3(search_grid), dim3(256), 0, st, sc->d_sargs + gi, (const f2*)g.d_rec,
                            (const float*)g.d_tedge, par);
         hipLaunchKernelGGL(k_search_exact, dim3(sc->exact_grid), dim3(256), 0, st, sc->d_sargs + gi, par);
+        HIP_TRY(hipEventRecord(ev[1], st));
         if (gi == 0)
           hipLaunchKernelGGL(k_search_finish, dim3(grid), dim3(256), 0, st, sc->d_sargs + gi, par);
         else
@@ -2247,8 +2248,9 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
                              0, st, shc, sc->dev, sc->d_sargs + gi, sc->d_rgb, par);
       } else {
         hipLaunchKernelGGL(scan_kernel, dim3(search_grid), dim3(256), 0, st, sc->d_sargs + gi, (const f2*)g.d_cone);
+        HIP_TRY(hipEventRecord(ev[1], st));
       }
-      HIP_TRY(hipEventRecord(e1, st));
+      HIP_TRY(hipEventRecord(ev[2], st));
       ++launches;
       return RTMI_OK;
     };
@@ -2261,9 +2263,13 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
       if ((rc = search_group(gi))) return rc;
     // the shade queue stays empty when the cone tree shades every triangle hit itself and the scene
     // lists nothing else that can be shaded (no sphere or light object, no top-level triangles)
-    if (!(use_tree && !has_top_runs && sc->n_plain_shadeable == 0))
-    hipLaunchKernelGGL(has_top_runs ? k_shade<true> : k_shade<false>, dim3(std::min(grid, 4 * sc->exact_grid)), dim3(256), 0, st, shc, sc->dev, sc->d_dirs, sc->d_tval, sc->d_q_shade, &sc->d_cnt->q_shade,
-                       sc->d_hit_id, sc->d_rgb, sc->d_cnt);
+    if (!(use_tree && !has_top_runs && sc->n_plain_shadeable == 0)) {
+      if (b0 == 0) HIP_TRY(hipEventRecord(sc->ev_c, st));  // timed for the first batch only (frames are one batch as a rule)
+      hipLaunchKernelGGL(has_top_runs ? k_shade<true> : k_shade<false>, dim3(std::min(grid, 4 * sc->exact_grid)), dim3(256), 0, st, shc, sc->dev, sc->d_dirs, sc->d_tval, sc->d_q_shade, &sc->d_cnt->q_shade,
+                         sc->d_hit_id, sc->d_rgb, sc->d_cnt);
+      if (b0 == 0) HIP_TRY(hipEventRecord(sc->ev_d, st));
+      shade_queue_launched = true;
+    }
     int npix = (int)(nb * BLK_PIX);
     hipLaunchKernelGGL(k_resolve, dim3((npix + 255) / 256), dim3(256), 0, st, fc, d_blk, npix, sc->d_hit_id, sc->d_rgb,
                        (const rtmi_object*)sc->d_objects, (unsigned char*)rgba_dev, (int*)hit_dev);
@@ -2273,6 +2279,7 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
   HIP_TRY(hipMemcpyAsync(sc->h_cnt, sc->d_cnt, sizeof(DevCounters), hipMemcpyDeviceToHost, st));
   sc->pend_launches = launches;
   sc->pend_live_samples = live_samples;
+  sc->pend_shade_timed = shade_queue_launched;
   sc->pend_cam = *cam;
   sc->pend_params = *p;
   sc->pend_rgba = rgba_dev;
@@ -2313,12 +2320,19 @@ static int32_t render_end_impl(rtmi_scene* sc, rtmi_counters* counters) {
     sc->pend_params.search = RTMI_SEARCH_CONE_TREE;
   }
   const DevCounters& hc = *sc->h_cnt;
-  float ms_total = 0.f, ms_search = 0.f;
+  float ms_total = 0.f, ms_search = 0.f, ms_shade = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms_total, sc->ev_a, sc->ev_b));
   for (size_t i = 0; i < sc->ev_used; ++i) {
     float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, sc->ev_pool[i].first, sc->ev_pool[i].second));
+    HIP_TRY(hipEventElapsedTime(&ms, sc->ev_pool[i][0], sc->ev_pool[i][1]));
     ms_search += ms;
+    HIP_TRY(hipEventElapsedTime(&ms, sc->ev_pool[i][1], sc->ev_pool[i][2]));
+    ms_shade += ms;
+  }
+  if (sc->pend_shade_timed) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, sc->ev_c, sc->ev_d));
+    ms_shade += ms;
   }
   if (counters) {
     const int64_t live_samples = sc->pend_live_samples;
@@ -2343,6 +2357,7 @@ static int32_t render_end_impl(rtmi_scene* sc, rtmi_counters* counters) {
     counters->tri_search_launches = sc->pend_launches;
     counters->tri_tests_primary_kernel = (int64_t)sum[C_TESTS_PRIMARY];
     counters->ms_primary_kernel = ms_search;
+    counters->ms_shade = ms_shade;
   }
   return RTMI_OK;
 }
