@@ -1041,7 +1041,8 @@ __device__ __forceinline__ void cand_flush(const SearchArgs* ap, const int2* sta
 // pushed but evaluated per lane: every (ray, slot) pair that passes becomes a candidate.
 template <int R>
 __global__ void __launch_bounds__(256, 6)
-k_search_tree(const SearchArgs* __restrict__ ap, const f2* __restrict__ rec, const float* __restrict__ edge_all, int parity) {
+k_search_tree(const SearchArgs* __restrict__ ap, const f2* __restrict__ rec, const float* __restrict__ edge_all,
+              const int* __restrict__ slot_pos, int parity) {
   __shared__ int2 stage_all[4][CAND_STAGE];
   const int nq = *ap->nq_ptr;
   const int lane = threadIdx.x & 63;
@@ -1099,7 +1100,7 @@ k_search_tree(const SearchArgs* __restrict__ ap, const f2* __restrict__ rec, con
         if (!__any(mq >= 1.0f) && !((always >> jj) & 1u)) continue;
         const float* m = edge + jj * EDGE_FLOATS;
         const float m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3], m4 = m[4], m5 = m[5], m6 = m[6], m7 = m[7], m8 = m[8];
-        const int g = ri * 8 + jj;
+        const int pos = slot_pos[ri * 8 + jj];  // the triangle's position in the group's list order
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           const float qv = h ? q[r].y : q[r].x;
@@ -1117,7 +1118,7 @@ k_search_tree(const SearchArgs* __restrict__ ap, const f2* __restrict__ rec, con
             fill = 0;
             __builtin_amdgcn_wave_barrier();
           }
-          if (pass) stage[fill + __popcll(bm & ((1ull << lane) - 1ull))] = make_int2(sid[r], g);
+          if (pass) stage[fill + __popcll(bm & ((1ull << lane) - 1ull))] = make_int2(sid[r], pos);
           fill += n;
         }
       }
@@ -1184,19 +1185,30 @@ k_search_exact(const SearchArgs* __restrict__ ap, int parity) {
     const int2* cand = ap->cand + (size_t)list * list_cap;
     const double* dirs = ap->dirs;
     const d3 o = rtx::ld3(ap->cam);
-    for (int i = part * blockDim.x + threadIdx.x; i < n; i += parts * blockDim.x) {
-      const int2 c = cand[i];
-      const int s = c.x, g = c.y;
+    // The entry of the NEXT step is fetched (with the triangle index it leads to) before the
+    // current one is evaluated: a step begins with a chain of dependent loads, and this way the
+    // chain of step k+1 runs under the arithmetic of step k.
+    const int stride = parts * blockDim.x;
+    const int* group = ap->group;
+    int i = part * blockDim.x + threadIdx.x;
+    int2 c = i < n ? cand[i] : make_int2(0, 0);
+    int ti = i < n ? group[c.y] : 0;
+    while (i < n) {
+      const int inext = i + stride;
+      const int2 cn = inext < n ? cand[inext] : c;
+      const int tin = group[cn.y];
+      const int s = c.x, pos = c.y;
       const double* dp = dirs + (size_t)s * 3;
-      const int ti = ap->tree.slot_tri[g];
-      if (ti < 0) continue;  // padding slot (its zero cone passes nothing; belt and braces)
       const rtmi_triangle& tr = ap->tris[ti];
       d3 P;
       double tv;
       n_exact += 1;
       if (rtx::tri_hit(rtx::ld3(tr.v[0]), rtx::ld3(tr.v[1]), rtx::ld3(tr.v[2]), ap->planes[ti], o,
                        rtx::mk(dp[0], dp[1], dp[2]), &tv, &P))
-        atomicMin(&ap->best_pos[s], ap->tree.slot_pos[g]);
+        atomicMin(&ap->best_pos[s], pos);
+      c = cn;
+      ti = tin;
+      i = inext;
     }
   }
   wave_count(ap->cnt, C_EXACT, (unsigned long long)n_exact);
@@ -1449,16 +1461,31 @@ k_shade_candidates(ShadeConst fc, SceneDev sc, const SearchArgs* __restrict__ ap
     const int n = cnt->cand_n[par][list][0];
     const int2* cand = ap->cand + (size_t)list * list_cap;
     const double* dirs = ap->dirs;
-    for (int i = part * blockDim.x + threadIdx.x; i < n; i += parts * blockDim.x) {
-      const int2 c = cand[i];
-      const int s = c.x, g = c.y;
-      if (ap->best_pos[s] != ap->tree.slot_pos[g]) continue;  // another triangle of this ray is listed earlier, or no hit
-      const int ti = ap->tree.slot_tri[g];
-      const double* dp = dirs + (size_t)s * 3;
-      const d3 d = rtx::mk(dp[0], dp[1], dp[2]);
-      const double tv = rtx::tri_t(sc.planes[ti], rtx::ld3(fc.cam), d);  // k_search_exact accepted this pair
-      ap->hit_id[s] = ti;
-      shade_sample<HAS_TOP>(fc, sc, s, d, ti, tv, rgb, &tl);
+    // as in k_search_exact: the next step's entry and what hangs on it are fetched one step ahead
+    const int stride = parts * blockDim.x;
+    const int* group = ap->group;
+    const int* best_pos = ap->best_pos;
+    int i = part * blockDim.x + threadIdx.x;
+    int2 c = i < n ? cand[i] : make_int2(0, 0);
+    int ti = i < n ? group[c.y] : 0;
+    int bp = i < n ? best_pos[c.x] : 0;
+    while (i < n) {
+      const int inext = i + stride;
+      const int2 cn = inext < n ? cand[inext] : c;
+      const int tin = group[cn.y];
+      const int bpn = best_pos[cn.x];
+      const int s = c.x;
+      if (bp == c.y) {  // else another triangle of this ray is listed earlier, or the pair was no hit
+        const double* dp = dirs + (size_t)s * 3;
+        const d3 d = rtx::mk(dp[0], dp[1], dp[2]);
+        const double tv = rtx::tri_t(sc.planes[ti], rtx::ld3(fc.cam), d);  // k_search_exact accepted this pair
+        ap->hit_id[s] = ti;
+        shade_sample<HAS_TOP>(fc, sc, s, d, ti, tv, rgb, &tl);
+      }
+      c = cn;
+      ti = tin;
+      bp = bpn;
+      i = inext;
     }
   }
   search_lists_retire(cnt, par);
@@ -2238,7 +2265,7 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
         const int par = launch_parity;
         launch_parity ^= 1;
         hipLaunchKernelGGL(tree_kernel, dim3(search_grid), dim3(256), 0, st, sc->d_sargs + gi, (const f2*)g.d_rec,
-                           (const float*)g.d_tedge, par);
+                           (const float*)g.d_tedge, (const int*)g.d_slot_pos, par);
         hipLaunchKernelGGL(k_search_exact, dim3(sc->exact_grid), dim3(256), 0, st, sc->d_sargs + gi, par);
         HIP_TRY(hipEventRecord(ev[1], st));
         if (gi == 0)
