@@ -237,6 +237,14 @@ int32_t rtmi_obj_material_count(const rtmi_obj_mesh* mesh);
 const rtmi_material* rtmi_obj_materials(const rtmi_obj_mesh* mesh);   /* owned by the mesh */
 const char* rtmi_obj_material_name(const rtmi_obj_mesh* mesh, int32_t index);
 
+/* ---- image output (host only) ----------------------------------------------------------- */
+
+/* Write the RGBA8 frame (4*width bytes per row, as rtmi_render fills it) as a binary PPM (RGB) or
+ * as an 8-bit RGBA PNG.  Stands in for the CGImage the reference builds from outputBitmap to show
+ * it (ViewController.swift:197-216). */
+int32_t rtmi_write_ppm(const char* path, const uint8_t* rgba, int32_t width, int32_t height);
+int32_t rtmi_write_png(const char* path, const uint8_t* rgba, int32_t width, int32_t height);
+
 #ifdef __cplusplus
 }
 #endif

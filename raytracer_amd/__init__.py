@@ -71,6 +71,9 @@ def lib():
         L.rtmi_obj_materials.argtypes = [C.c_void_p]
         L.rtmi_obj_material_name.restype = C.c_char_p
         L.rtmi_obj_material_name.argtypes = [C.c_void_p, C.c_int32]
+        for name in ("rtmi_write_ppm", "rtmi_write_png"):
+            getattr(L, name).restype = C.c_int32
+            getattr(L, name).argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]
         if L.rtmi_abi_version() != _abi.RTMI_ABI_VERSION:
             raise ImportError("librtmi.so ABI version does not match raytracer_amd/_abi.py")
         _lib = L
@@ -118,6 +121,14 @@ def load_obj(obj_path, mtl_path=None):
         return tris, mats, names, L.rtmi_obj_vertex_count(h)
     finally:
         lib().rtmi_obj_free(h)
+
+
+def write_image(path, rgba: np.ndarray):
+    """Write an [H,W,4] uint8 frame as .ppm or .png (rtmi_write_ppm / rtmi_write_png)."""
+    rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
+    assert rgba.ndim == 3 and rgba.shape[2] == 4
+    fn = lib().rtmi_write_ppm if str(path).lower().endswith(".ppm") else lib().rtmi_write_png
+    _check(fn(os.fsencode(path), rgba.ctypes.data, rgba.shape[1], rgba.shape[0]), "rtmi_write_image")
 
 
 class Scene:
