@@ -1,0 +1,96 @@
+// Swift face of librtmi.so for the reference's types.  NOT compiled in this repository's
+// container (no Swift toolchain); written against include/rtmi.h.
+//
+// The value types below carry exactly the stored properties of the reference's classes
+// (Renderables.swift, ObjLoader.swift, Utilities.swift); a maintainer would pass the reference's own
+// objects instead and delete these.
+import CRtmi
+
+public struct V3 { public var x, y, z: Double; public init(_ x: Double, _ y: Double, _ z: Double) { self.x = x; self.y = y; self.z = z } }
+public struct Color { public var red, green, blue: Double; public init(_ r: Double, _ g: Double, _ b: Double) { red = r; green = g; blue = b } }
+public struct MaterialValues { public var specularExponent, dissolution: Double; public var illumination: Int32; public var diffuse, ambient, specular: Color }
+public struct LightValues { public var location: V3; public var specular, diffuse: Color }
+
+public enum SceneObject {
+    case sphere(center: V3, radius: Double, material: MaterialValues?)
+    case boundingSphere(center: V3, radius: Double, material: MaterialValues?, children: [(V3, V3, V3, MaterialValues?)])
+    case triangle(V3, V3, V3, MaterialValues?)
+    case light(index: Int)
+}
+
+func tuple(_ v: V3) -> (Double, Double, Double) { (v.x, v.y, v.z) }
+func tuple(_ c: Color) -> (Double, Double, Double) { (c.red, c.green, c.blue) }
+
+/// A scene resident on one GPU (rtmi_scene_create / rtmi_scene_destroy).  Order of `objects` is
+/// preserved: the first intersection in list order wins, as in RayTracingFunctions.swift:41-43.
+public final class RtmiScene {
+    var handle: OpaquePointer?
+
+    public init(lights: [LightValues], objects: [SceneObject], device: Int32 = 0) {
+        let cLights = lights.map { rtmi_light(loc: tuple($0.location), specular: tuple($0.specular), diffuse: tuple($0.diffuse)) }
+        var cMaterials: [rtmi_material] = []
+        var cTriangles: [rtmi_triangle] = []
+        var cObjects: [rtmi_object] = []
+        func materialIndex(_ m: MaterialValues?) -> Int32 {
+            guard let m = m else { return -1 }  // nil stays nil
+            cMaterials.append(rtmi_material(Ns: m.specularExponent, d: m.dissolution, illum: m.illumination, pad_: 0,
+                                            Kd: tuple(m.diffuse), Ka: tuple(m.ambient), Ks: tuple(m.specular)))
+            return Int32(cMaterials.count - 1)
+        }
+        func append(_ a: V3, _ b: V3, _ c: V3, _ m: MaterialValues?) {
+            cTriangles.append(rtmi_triangle(v: (tuple(a), tuple(b), tuple(c)), material: materialIndex(m), pad_: 0))
+        }
+        for o in objects {
+            switch o {
+            case let .sphere(c, r, m):
+                cObjects.append(rtmi_object(kind: Int32(RTMI_SPHERE.rawValue), material: materialIndex(m), center: tuple(c), radius: r, first: 0, count: 0))
+            case let .boundingSphere(c, r, m, children):
+                let first = Int64(cTriangles.count)
+                for t in children { append(t.0, t.1, t.2, t.3) }
+                cObjects.append(rtmi_object(kind: Int32(RTMI_BOUNDING_SPHERE.rawValue), material: materialIndex(m), center: tuple(c), radius: r,
+                                            first: first, count: Int64(cTriangles.count) - first))
+            case let .triangle(a, b, c, m):
+                cObjects.append(rtmi_object(kind: Int32(RTMI_TRIANGLES.rawValue), material: -1, center: (0, 0, 0), radius: 0,
+                                            first: Int64(cTriangles.count), count: 1))
+                append(a, b, c, m)
+            case let .light(index):
+                cObjects.append(rtmi_object(kind: Int32(RTMI_LIGHT.rawValue), material: -1, center: (0, 0, 0), radius: 0, first: Int64(index), count: 0))
+            }
+        }
+        cLights.withUnsafeBufferPointer { lp in
+            cMaterials.withUnsafeBufferPointer { mp in
+                cObjects.withUnsafeBufferPointer { op in
+                    cTriangles.withUnsafeBufferPointer { tp in
+                        var desc = rtmi_scene_desc(lights: lp.baseAddress, n_lights: Int32(lp.count), n_materials: Int32(mp.count),
+                                                   materials: mp.baseAddress, objects: op.baseAddress, triangles: tp.baseAddress,
+                                                   n_objects: Int64(op.count), n_triangles: Int64(tp.count))
+                        let rc = rtmi_scene_create(&desc, device, &handle)
+                        precondition(rc == RTMI_OK.rawValue, String(cString: rtmi_last_error()))
+                    }
+                }
+            }
+        }
+    }
+
+    deinit { rtmi_scene_destroy(handle) }
+}
+
+/// raytraceWorld (RayTracingFunctions.swift:145-180).  imageWidth/imageHeight are the reference's
+/// globals (ViewController.swift:13-14); the reference ignores its imageWidthPixels/imageHeightPixels
+/// arguments (:170) and so does this.
+public func raytraceWorld(camera: V3, cameraDirection: V3, focalLength: Double, imageWidth: Int, imageHeight: Int,
+                          pixelSubdivision: Double = 1, ambientLight: Color, scene: RtmiScene,
+                          outputBitmap: inout [UInt8], pixelDone: (() -> Void)? = nil) {
+    var cam = rtmi_camera(pos: tuple(camera), dir: tuple(cameraDirection), focal_length: focalLength)
+    var p = rtmi_params()
+    p.width = Int32(imageWidth)
+    p.height = Int32(imageHeight)
+    p.pixel_subdivision = pixelSubdivision  // :170 hard-codes 1; 0.5 = 4 samples per pixel, 0.25 = 16
+    p.ambient = tuple(ambientLight)
+    p.hit_policy = Int32(RTMI_HIT_LIST_ORDER.rawValue)
+    p.search = Int32(RTMI_SEARCH_CONE_TREE.rawValue)
+    var counters = rtmi_counters()
+    let rc = outputBitmap.withUnsafeMutableBufferPointer { rtmi_render(scene.handle, &cam, &p, $0.baseAddress, nil, &counters) }
+    precondition(rc == RTMI_OK.rawValue, String(cString: rtmi_last_error()))
+    for _ in 0..<counters.samples { pixelDone?() }  // progress is reported after the frame, not per pixel
+}
