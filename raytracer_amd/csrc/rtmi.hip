@@ -63,7 +63,6 @@ constexpr int TRI_BATCH = 8;        // triangles per scalar-load batch of the co
 constexpr int CONE_DWORDS = 32;     // per batch: 4 pairs x 3 components x (tri a, tri b) + flag + pad
 constexpr int CONE_FLAG = 24;       // dword index of the batch's "always look closer" flag
 constexpr int EDGE_FLOATS = 9;      // per triangle: 3 scaled edge-plane vectors
-constexpr int GSPH_BATCH = 4;       // triangles per scalar-load batch of the general-origin sphere test
 constexpr int GST2_FLOATS = 32;     // per triangle: plane (4) + bounds (5) + 3 x (w, e) (18), padded
 
 struct FrameConst {
@@ -115,10 +114,8 @@ struct SceneDev {
   int n_objects, n_lights, n_sphere_like;
   long long n_top_tris;
   // general-origin filter of the top-level triangle runs (secondary rays), built once per scene
-  const float* gsph;     // per 4 triangles: 16 floats, see k_pack_general
-  const float* gst2;     // per triangle: GST2_FLOATS floats
   const int* top_group;  // top-level ordinal -> triangle index
-  const int* run_start;  // object index -> first top-level ordinal of its run
+  const int* tri_owner;  // triangle -> list index of the object (run) that lists it
   double c0[3];          // centre the FP32 filter coordinates are relative to
 };
 
@@ -368,13 +365,9 @@ __global__ void k_pack_write(const rtmi_triangle* __restrict__ tris, const int* 
 // reflection and shadow rays, RayTracingFunctions.swift:212,236).  All FP32 values are relative
 // to the centre c0; r_o1 bounds |o - c0|_1 over every possible ray origin (scene bounds).
 //
-// (1) Sphere test, packed two triangles per instruction.  With c the centroid, rho the largest
-//     vertex distance from it and m = c - o, a hit needs the ray's LINE within rho of c:
-//     (d.m)^2 + rho^2 - |m|^2 >= 0.  Expanded so that every term is a dot product with a
-//     per-triangle scalar operand: A = d.c - d.o, T = A*A + (2 c.o - |o|^2), nominate iff
-//     T + nK >= 0 with nK = rho^2 + delta - |c|^2.  delta = 64*2^-24*(|c|_1 + r_o1)^2 exceeds the FP32
-//     evaluation error of T (about 40*2^-24*(|c|_1+|o|_1)^2).
-// (2) Plane and edge tests (Pluecker form), per nominated triangle:
+// (1) Sphere tests: the bounding-sphere tree over the runs' triangles (tree_sphere_records in
+//     rtmi_tree.h, built on the host), walked by top_tree_trace below.
+// (2) Plane and edge tests (Pluecker form), per nominated triangle, prepared here:
 //       n.d <= Ea                        (Renderables.swift:146, front face)
 //       n.o - cpl >= -Eb                 (t > 0, :150-152, given n.d < 0)
 //       d.w_i + (o x d).e_i <= E_i       (:158-163; w_i = v_i x v_j, e_i = v_j - v_i, because
@@ -382,26 +375,15 @@ __global__ void k_pack_write(const rtmi_triangle* __restrict__ tris, const int* 
 //     each bound 16*2^-24 times the sum of the magnitudes that enter the FP32 evaluation.
 // Pairs that pass everything are decided by rtx::tri_hit in FP64.
 __global__ void k_pack_general(const rtmi_triangle* __restrict__ tris, const int* __restrict__ group, int n, d3 c0,
-                               double r_o1, float* gsph, float* gst2) {
+                               double r_o1, float* gst2) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const rtmi_triangle& t = tris[group[i]];
   d3 v[3];
   for (int q = 0; q < 3; ++q) v[q] = rtx::sub(rtx::ld3(t.v[q]), c0);
   const double eps32 = 5.9604644775390625e-08;  // 2^-24
-  // (1)
   d3 c = rtx::mk((v[0].x + v[1].x + v[2].x) / 3.0, (v[0].y + v[1].y + v[2].y) / 3.0, (v[0].z + v[1].z + v[2].z) / 3.0);
-  double rho2 = 0;
-  for (int q = 0; q < 3; ++q) rho2 = fmax(rho2, rtx::len_squared(rtx::sub(v[q], c)));
   double s1 = fabs(c.x) + fabs(c.y) + fabs(c.z) + r_o1;
-  double nK = rho2 * (1.0 + 1e-6) + 64.0 * eps32 * s1 * s1 - rtx::len_squared(c);
-  float fx = (float)c.x, fy = (float)c.y, fz = (float)c.z, fk = (float)nK;
-  if (!isfinite(fx) || !isfinite(fy) || !isfinite(fz) || !isfinite(fk)) { fx = fy = fz = 0.f; fk = 3.0e38f; }  // always nominate
-  {
-    int b = i / GSPH_BATCH, j = i % GSPH_BATCH;
-    float* dst = gsph + (size_t)b * 16 + (j >> 1) * 8 + (j & 1);
-    dst[0] = fx; dst[2] = fy; dst[4] = fz; dst[6] = fk;
-  }
   // (2)
   float* o = gst2 + (size_t)i * GST2_FLOATS;
   d3 e01 = rtx::sub(v[1], v[0]), e02 = rtx::sub(v[2], v[0]);
@@ -461,47 +443,93 @@ __device__ inline int first_sphere_like(const SceneDev& sc, d3 o, d3 d) {
   return -1;
 }
 
-// First hit in list order of a general-origin ray among the top-level ordinals [lo, hi): the
-// lane = ray brute-force scan with the three-stage filter prepared by k_pack_general.  Called
-// from divergent shading code: the wave-level votes below only see the lanes that are tracing.
-__device__ inline long long first_tri_filtered(const SceneDev& sc, int lo, int hi, d3 o, d3 d, double* t_out,
-                                               d3* P_out, unsigned long long* n_tests) {
+// The bounding-sphere tree of the top-level triangle runs as the shading kernels see it.  The
+// three arrays are separate __restrict__ kernel arguments (that is what lets the compiler fetch
+// records through scalar loads in kernels that also store).
+struct TopTreeRef {
+  const f2* rec;        // sphere records, all levels (tree_sphere_records)
+  const float* gst2;    // per top-level ordinal: plane and edge operands (k_pack_general)
+  const int* slot_pos;  // slot -> top-level ordinal (= position among the top-level triangles)
+  int ltop, n_root, n_slots;
+  int off[TREE_MAX_LEVELS];
+};
+
+// The scalar part of TopTreeRef, passed to the kernels by value.
+struct TopTreeArgs {
+  int ltop, n_root, n_slots;
+  int off[TREE_MAX_LEVELS];
+};
+
+__device__ inline TopTreeRef make_top_tree(const TopTreeArgs& a, const f2* rec, const float* gst2, const int* slot_pos) {
+  TopTreeRef t;
+  t.rec = rec; t.gst2 = gst2; t.slot_pos = slot_pos;
+  t.ltop = a.ltop; t.n_root = a.n_root; t.n_slots = a.n_slots;
+#pragma unroll
+  for (int l = 0; l < TREE_MAX_LEVELS; ++l) t.off[l] = a.off[l];
+  return t;
+}
+
+// A general-origin ray (reflection or shadow ray) against ALL top-level triangles: the ordinal of
+// the hit that comes first in list order (any_only: of some hit), or -1.  The lanes that call this
+// together walk the tree together, like k_search_tree: a record of eight bounding spheres is
+// evaluated for every calling lane's own ray (packed line-sphere test, two spheres per
+// instruction), and a child is entered if some lane passes.  At a leaf the per-triangle cascade
+// of k_pack_general follows, then rtx::tri_hit in FP64.  Called from divergent shading code: the
+// wave-level votes only see the lanes that are tracing.
+__device__ inline int top_tree_trace(const SceneDev& sc, const TopTreeRef& T, d3 o, d3 d, bool any_only, double* t_out,
+                                     d3* P_out, unsigned long long* n_tests) {
   const float ox = (float)(o.x - sc.c0[0]), oy = (float)(o.y - sc.c0[1]), oz = (float)(o.z - sc.c0[2]);
-  float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
+  const float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
   const float ndo = -(dx * ox + dy * oy + dz * oz);
   const float noo = -(ox * ox + oy * oy + oz * oz);
   const float o2x = 2.0f * ox, o2y = 2.0f * oy, o2z = 2.0f * oz;
-  // o x d for the edge tests
-  const float mx_ = oy * dz - oz * dy, my_ = oz * dx - ox * dz, mz_ = ox * dy - oy * dx;
-  long long found = -1;
-  const f2* sph = reinterpret_cast<const f2*>(sc.gsph);
-  const int b0 = lo / GSPH_BATCH, b1 = (hi + GSPH_BATCH - 1) / GSPH_BATCH;
-  for (int b = b0; b < b1; ++b) {
-    const f2* p = sph + (size_t)b * 8;
-    float mx = -3.0e38f;
+  const float mx_ = oy * dz - oz * dy, my_ = oz * dx - ox * dz, mz_ = ox * dy - oy * dx;  // o x d for the edge tests
+  const f2 X = {dx, dx}, Y = {dy, dy}, Z = {dz, dz}, N0 = {ndo, ndo};
+  const f2 OX = {o2x, o2x}, OY = {o2y, o2y}, OZ = {o2z, o2z}, N1 = {noo, noo};
+  int best = 0x7fffffff;  // ordinal of the best hit so far
+  unsigned int leaf_visits = 0;
+
+  // line-sphere values of the record's pair `pr`: passes iff !(U < 0)
+  auto pair_u = [&](const f2* rp, int pr) {
+    const f2 cx = rp[pr * 4 + 0], cy = rp[pr * 4 + 1], cz = rp[pr * 4 + 2], nk = rp[pr * 4 + 3];
+    f2 A = __builtin_elementwise_fma(cz, Z, __builtin_elementwise_fma(cy, Y, __builtin_elementwise_fma(cx, X, N0)));
+    f2 B = __builtin_elementwise_fma(cz, OZ, __builtin_elementwise_fma(cy, OY, __builtin_elementwise_fma(cx, OX, N1)));
+    return __builtin_elementwise_fma(A, A, B) + nk;
+  };
+  auto level_off = [&](int lvl) {
+    return lvl == 1 ? T.off[1] : lvl == 2 ? T.off[2] : lvl == 3 ? T.off[3] : lvl == 4 ? T.off[4] : lvl == 5 ? T.off[5]
+         : lvl == 6 ? T.off[6] : T.off[7];
+  };
+  auto eval = [&](int lvl, int ri) -> unsigned {
+    const f2* rp = T.rec + (size_t)(level_off(lvl) + ri) * (REC_DWORDS / 2);
+    const bool live = !any_only || best == 0x7fffffff;
+    unsigned mask = 0;
 #pragma unroll
-    for (int pr = 0; pr < 2; ++pr) {
-      const f2 cx = p[pr * 4 + 0], cy = p[pr * 4 + 1], cz = p[pr * 4 + 2], nk = p[pr * 4 + 3];
-      f2 X = {dx, dx}, Y = {dy, dy}, Z = {dz, dz}, N0 = {ndo, ndo};
-      f2 A = __builtin_elementwise_fma(cz, Z, __builtin_elementwise_fma(cy, Y, __builtin_elementwise_fma(cx, X, N0)));
-      f2 OX = {o2x, o2x}, OY = {o2y, o2y}, OZ = {o2z, o2z}, N1 = {noo, noo};
-      f2 B = __builtin_elementwise_fma(cz, OZ, __builtin_elementwise_fma(cy, OY, __builtin_elementwise_fma(cx, OX, N1)));
-      f2 U = __builtin_elementwise_fma(A, A, B) + nk;
-      mx = __builtin_fmaxf(__builtin_fmaxf(mx, U.x), U.y);
+    for (int pr = 0; pr < 4; ++pr) {
+      f2 U = pair_u(rp, pr);
+      if (__any(live && !(U.x < 0.0f))) mask |= 1u << (2 * pr);
+      if (__any(live && !(U.y < 0.0f))) mask |= 2u << (2 * pr);
     }
-    if (__builtin_expect(__any(mx >= 0.0f), 0)) {
-      for (int j = 0; j < GSPH_BATCH; ++j) {
-        const int g = b * GSPH_BATCH + j;
-        if (g < lo) continue;
-        if (g >= hi) break;
-        const float* q = reinterpret_cast<const float*>(p) + (j >> 1) * 8 + (j & 1);
-        const float cx = q[0], cy = q[2], cz = q[4], nk = q[6];
-        float A = __builtin_fmaf(cz, dz, __builtin_fmaf(cy, dy, __builtin_fmaf(cx, dx, ndo)));
-        float B = __builtin_fmaf(cz, o2z, __builtin_fmaf(cy, o2y, __builtin_fmaf(cx, o2x, noo)));
-        float U = __builtin_fmaf(A, A, B) + nk;
-        bool cand = !(U < 0.0f) && found < 0;  // NaN (finished ray) is excluded by found < 0
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)mask);
+  };
+  auto leaf = [&](int ri) {
+    if (ri * 8 >= T.n_slots) return;  // cannot happen (absent nodes never pass); keeps a bad record from becoming a bad address
+    const f2* rp = T.rec + (size_t)(T.off[0] + ri) * (REC_DWORDS / 2);
+    const bool live = !any_only || best == 0x7fffffff;
+    if (live) ++leaf_visits;
+#pragma unroll
+    for (int pr = 0; pr < 4; ++pr) {
+      f2 U = pair_u(rp, pr);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float u = h ? U.y : U.x;
+        bool cand = live && !(u < 0.0f);
         if (!__any(cand)) continue;
-        const float* s2 = sc.gst2 + (size_t)g * GST2_FLOATS;
+        const int g = T.slot_pos[ri * 8 + pr * 2 + h];  // top-level ordinal
+        if (g < 0) continue;                            // padding slot (its sphere passes nothing; belt and braces)
+        cand = cand && (any_only ? best == 0x7fffffff : g < best);  // a later list position cannot replace the hit
+        if (!__any(cand)) continue;
+        const float* s2 = T.gst2 + (size_t)g * GST2_FLOATS;
         {
           const float nx = s2[0], ny = s2[1], nz = s2[2], cpl = s2[3], Ea = s2[4], Eb = s2[5];
           float nd = __builtin_fmaf(nz, dz, __builtin_fmaf(ny, dy, nx * dx));
@@ -523,27 +551,59 @@ __device__ inline long long first_tri_filtered(const SceneDev& sc, int lo, int h
           double t;
           d3 P;
           if (rtx::tri_hit(rtx::ld3(tr.v[0]), rtx::ld3(tr.v[1]), rtx::ld3(tr.v[2]), sc.planes[ti], o, d, &t, &P)) {
-            found = ti;
+            best = g;
             *t_out = t;
             *P_out = P;
-            *n_tests += (unsigned long long)(g - lo + 1);  // list positions this ray consumed
-            dx = dy = dz = __builtin_nanf("");  // this ray nominates nothing from here on
           }
         }
       }
-      if (__all(found >= 0)) break;
+    }
+  };
+
+  const int ltop = T.ltop;
+  bool done = false;
+  for (int t = 0; t < T.n_root && !done; ++t) {
+    if (ltop == 0) {
+      leaf(t);
+      done = any_only && !__any(best == 0x7fffffff);
+      continue;
+    }
+    int lvl = ltop, ri = t;
+    unsigned long long masks = (unsigned long long)eval(lvl, ri) << (8 * lvl);
+    for (;;) {
+      const unsigned cur = (unsigned)(masks >> (8 * lvl)) & 0xffu;
+      if (cur == 0) {
+        if (lvl == ltop) break;
+        ++lvl;
+        ri >>= 3;
+        continue;
+      }
+      const int c = __builtin_ctz(cur);
+      masks &= ~(1ull << (8 * lvl + c));
+      const int child = ri * 8 + c;
+      if (lvl == 1) {
+        leaf(child);
+        if (any_only && !__any(best == 0x7fffffff)) { done = true; break; }  // every tracing lane has its hit
+      } else {
+        --lvl;
+        ri = child;
+        masks |= (unsigned long long)eval(lvl, ri) << (8 * lvl);
+      }
     }
   }
-  if (found < 0) *n_tests += (unsigned long long)(hi - lo);
-  return found;
+  *n_tests += 8ull * leaf_visits;  // (ray, triangle) sphere tests this lane's ray took part in
+  return best == 0x7fffffff ? -1 : best;
 }
 
 // traceRay over the whole top-level list (RayTracingFunctions.swift:37-44) for a secondary
 // ray: intersections[0] if want_first, and whether any non-bounding object is hit.
 template <bool HAS_TOP>
-__device__ inline bool trace_top_secondary(const SceneDev& sc, d3 o, d3 d, bool want_first, Hit* h,
+__device__ inline bool trace_top_secondary(const SceneDev& sc, const TopTreeRef& tt, d3 o, d3 d, bool want_first, Hit* h,
                                            bool* any_non_bounding, unsigned long long* n_tests) {
   bool found = false, anb = false;
+  // spheres, bounding spheres and lights first, in list order: for a shadow ray the first
+  // non-bounding hit settles the question and the triangles need not be searched
+  int first_obj = 0x7fffffff;  // list index of the first sphere-like hit (want_first)
 #pragma nounroll
   for (int k = 0; k < sc.n_objects; ++k) {
     if (want_first ? found : anb) break;
@@ -551,10 +611,10 @@ __device__ inline bool trace_top_secondary(const SceneDev& sc, d3 o, d3 d, bool 
     if (ob.kind == RTMI_SPHERE || ob.kind == RTMI_BOUNDING_SPHERE) {
       double t;
       d3 P, n;
-      if (want_first && !found) {
+      if (want_first) {
         if (rtx::sphere_first_raw(rtx::ld3(ob.center), ob.radius, o, d, &t, &P, &n)) {
           found = true;
-          if (ob.kind == RTMI_SPHERE) anb = true;
+          first_obj = k;
           // without a material only the SIGN of normal.light is ever read (calculate_lighting)
           h->n_unit = ob.material >= 0;
           h->P = P; h->n = h->n_unit ? rtx::normalize(n) : n; h->t = t; h->has_normal = 1;
@@ -563,28 +623,34 @@ __device__ inline bool trace_top_secondary(const SceneDev& sc, d3 o, d3 d, bool 
       } else if (ob.kind == RTMI_SPHERE) {
         if (rtx::sphere_any(rtx::ld3(ob.center), ob.radius, o, d)) anb = true;
       }
-    } else if (HAS_TOP && ob.kind == RTMI_TRIANGLES) {
-      double t;
-      d3 P;
-      const int lo = sc.run_start[k];
-      long long i = first_tri_filtered(sc, lo, lo + (int)ob.count, o, d, &t, &P, n_tests);
-      if (i >= 0) {
-        anb = true;
-        if (!found) {
-          found = true;
-          const TriPlane pl = sc.planes[i];
-          h->P = P; h->n = rtx::mk(pl.nx, pl.ny, pl.nz); h->t = t; h->has_normal = 1; h->n_unit = 1;
-          h->material = sc.tris[i].material; h->id = (int)i;
-        }
-      }
     } else if (ob.kind == RTMI_LIGHT) {
       double t;
       d3 P;
       if (rtx::light_hit(rtx::ld3(sc.lights[ob.first].loc), o, d, &t, &P)) {
         anb = true;
-        if (!found) {
+        if (want_first) {
           found = true;
+          first_obj = k;
           h->P = P; h->t = t; h->has_normal = 0; h->n_unit = 1; h->material = -1; h->id = -2 - k;
+        }
+      }
+    }
+  }
+  if constexpr (HAS_TOP) {
+    // the top-level triangles: one walk for all runs; a triangle hit wins over the sphere-like
+    // hit if its run is listed earlier (RTF:41-43: the first intersection in list order)
+    if (want_first || !anb) {
+      double t;
+      d3 P;
+      const int g = top_tree_trace(sc, tt, o, d, !want_first, &t, &P, n_tests);
+      if (g >= 0) {
+        anb = true;
+        const int ti = sc.top_group[g];
+        if (want_first && sc.tri_owner[ti] < first_obj) {
+          found = true;
+          const TriPlane pl = sc.planes[ti];
+          h->P = P; h->n = rtx::mk(pl.nx, pl.ny, pl.nz); h->t = t; h->has_normal = 1; h->n_unit = 1;
+          h->material = sc.tris[ti].material; h->id = ti;
         }
       }
     }
@@ -1288,7 +1354,7 @@ __device__ inline int count_facing_lights(const SceneDev& sc, d3 P, d3 n, bool n
 }
 
 template <bool REFLECT, bool HAS_TOP>
-__device__ RGBd calculate_lighting(const SceneDev& sc, const ShadeConst& fc, const Hit& is, d3 camera,
+__device__ RGBd calculate_lighting(const SceneDev& sc, const TopTreeRef& tt, const ShadeConst& fc, const Hit& is, d3 camera,
                                    unsigned long long* n_refl, unsigned long long* n_shadow,
                                    unsigned long long* n_tests, unsigned long long* n_elided) {
   d3 surface_point = is.P;
@@ -1322,8 +1388,8 @@ __device__ RGBd calculate_lighting(const SceneDev& sc, const ShadeConst& fc, con
     Hit rh;
     bool anb;
     *n_refl += 1;
-    if (trace_top_secondary<HAS_TOP>(sc, surface_point, reflection, true, &rh, &anb, n_tests)) {
-      contribution = calculate_lighting<false, HAS_TOP>(sc, fc, rh, surface_point, n_refl, n_shadow, n_tests, n_elided);
+    if (trace_top_secondary<HAS_TOP>(sc, tt, surface_point, reflection, true, &rh, &anb, n_tests)) {
+      contribution = calculate_lighting<false, HAS_TOP>(sc, tt, fc, rh, surface_point, n_refl, n_shadow, n_tests, n_elided);
     }
     I.r = I.r + contribution.r;
     I.g = I.g + contribution.g;
@@ -1346,7 +1412,7 @@ __device__ RGBd calculate_lighting(const SceneDev& sc, const ShadeConst& fc, con
     Hit dummy;
     bool anb = false;
     *n_shadow += 1;
-    trace_top_secondary<HAS_TOP>(sc, surface_point, point_to_light, false, &dummy, &anb, n_tests);
+    trace_top_secondary<HAS_TOP>(sc, tt, surface_point, point_to_light, false, &dummy, &anb, n_tests);
     if (anb) continue;           // RTF:241
     if (!has_material) continue; // RTF:245
     double lr = light.diffuse[0], lg = light.diffuse[1], lb = light.diffuse[2];
@@ -1383,8 +1449,8 @@ __device__ inline void shade_tally_flush(DevCounters* cnt, const ShadeTally& t) 
 // Shade sample s whose primary ray (direction d) hit `id` (triangle index, or -2 - object index);
 // t_tri is the triangle's intersection parameter.
 template <bool HAS_TOP>
-__device__ __forceinline__ void shade_sample(const ShadeConst& fc, const SceneDev& sc, int s, d3 d, int id, double t_tri,
-                                             double* rgb, ShadeTally* tl) {
+__device__ __forceinline__ void shade_sample(const ShadeConst& fc, const SceneDev& sc, const TopTreeRef& tt, int s, d3 d,
+                                             int id, double t_tri, double* rgb, ShadeTally* tl) {
   d3 cam = rtx::ld3(fc.cam);
   Hit h;
   bool ok = false;
@@ -1419,7 +1485,7 @@ __device__ __forceinline__ void shade_sample(const ShadeConst& fc, const SceneDe
   RGBd c = {0.0, 0.0, 0.0};
   if (ok) {
     tl->n_hit += 1;
-    c = calculate_lighting<true, HAS_TOP>(sc, fc, h, cam, &tl->n_refl, &tl->n_shadow, &tl->n_tests, &tl->n_elided);
+    c = calculate_lighting<true, HAS_TOP>(sc, tt, fc, h, cam, &tl->n_refl, &tl->n_shadow, &tl->n_tests, &tl->n_elided);
   }
   rgb[(size_t)s * 3 + 0] = c.r;
   rgb[(size_t)s * 3 + 1] = c.g;
@@ -1430,16 +1496,18 @@ __device__ __forceinline__ void shade_sample(const ShadeConst& fc, const SceneDe
 // that scan is left out of the instantiation for scenes without such runs).
 template <bool HAS_TOP>
 __global__ void __launch_bounds__(256)
-k_shade(ShadeConst fc, SceneDev sc, const double* __restrict__ dirs,
+k_shade(ShadeConst fc, SceneDev sc, TopTreeArgs ta, const f2* __restrict__ trec, const float* __restrict__ gst2,
+        const int* __restrict__ tslot_pos, const double* __restrict__ dirs,
         const double* __restrict__ tval, const int* __restrict__ q_shade,
         const int* __restrict__ nq_ptr, const int* __restrict__ hit_id, double* rgb, DevCounters* cnt) {
+  const TopTreeRef tt = make_top_tree(ta, trec, gst2, tslot_pos);
   ShadeTally tl;
   const int nq = *nq_ptr;
   for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
     int s = q_shade[q];
     d3 d = rtx::mk(dirs[(size_t)s * 3 + 0], dirs[(size_t)s * 3 + 1], dirs[(size_t)s * 3 + 2]);
     int id = hit_id[s];
-    shade_sample<HAS_TOP>(fc, sc, s, d, id, id >= 0 ? tval[s] : 0.0, rgb, &tl);
+    shade_sample<HAS_TOP>(fc, sc, tt, s, d, id, id >= 0 ? tval[s] : 0.0, rgb, &tl);
   }
   shade_tally_flush(cnt, tl);
 }
@@ -1452,7 +1520,9 @@ k_shade(ShadeConst fc, SceneDev sc, const double* __restrict__ dirs,
 // without a hit keep the bounding object's marker in hit_id; k_resolve reads that as a miss.
 template <bool HAS_TOP>
 __global__ void __launch_bounds__(256, HAS_TOP ? 2 : 4)
-k_shade_candidates(ShadeConst fc, SceneDev sc, const SearchArgs* __restrict__ ap, double* rgb, int par) {
+k_shade_candidates(ShadeConst fc, SceneDev sc, TopTreeArgs ta, const f2* __restrict__ trec, const float* __restrict__ gst2,
+                   const int* __restrict__ tslot_pos, const SearchArgs* __restrict__ ap, double* rgb, int par) {
+  const TopTreeRef tt = make_top_tree(ta, trec, gst2, tslot_pos);
   DevCounters* cnt = ap->cnt;
   ShadeTally tl;
   if (!cnt->overflow) {
@@ -1480,7 +1550,7 @@ k_shade_candidates(ShadeConst fc, SceneDev sc, const SearchArgs* __restrict__ ap
         const d3 d = rtx::mk(dp[0], dp[1], dp[2]);
         const double tv = rtx::tri_t(sc.planes[ti], rtx::ld3(fc.cam), d);  // k_search_exact accepted this pair
         ap->hit_id[s] = ti;
-        shade_sample<HAS_TOP>(fc, sc, s, d, ti, tv, rgb, &tl);
+        shade_sample<HAS_TOP>(fc, sc, tt, s, d, ti, tv, rgb, &tl);
       }
       c = cn;
       ti = tin;
@@ -1549,6 +1619,7 @@ struct TriGroup {
   float* d_tedge = nullptr;
   NodeCone* d_nodes = nullptr;
   unsigned int* d_ticket = nullptr;
+  TreeHost tree_host;  // host copy of the slot order, kept until the scene is built
   // which operands the device holds: 0 none, 1 cone tree, 2 list scan -- and for which camera position
   int packed_for = 0;
   double packed_cam[3] = {0, 0, 0};
@@ -1567,9 +1638,9 @@ struct rtmi_scene {
   rtmi_triangle* d_tris = nullptr;
   TriPlane* d_planes = nullptr;
   int* d_tri_owner = nullptr;
-  float* d_gsph = nullptr;      // general-origin filter of the top-level runs
-  float* d_gst2 = nullptr;
-  int* d_run_start = nullptr;
+  float* d_trec = nullptr;      // bounding-sphere records of the top-level runs (secondary rays)
+  float* d_gst2 = nullptr;      // their per-triangle plane and edge operands
+  TopTreeArgs top_args{};
   std::vector<TriGroup> groups;  // [0] = top-level runs (may be empty), then bounding objects
   SceneDev dev{};
   // per-batch work buffers, grown on demand
@@ -1662,7 +1733,7 @@ static int32_t alloc_group(TriGroup& g, const std::vector<int>& idx, const rtmi_
   HIP_TRY(hipMalloc(&g.d_npacked, sizeof(int)));
   HIP_TRY(hipMemset(g.d_npacked, 0, sizeof(int)));
 
-  TreeHost th;
+  TreeHost& th = g.tree_host;
   tree_build_host(tris, idx, &th);
   g.tree = th.dev;
   const size_t ns = th.slot_tri.size();
@@ -1751,7 +1822,7 @@ extern "C" void rtmi_scene_destroy(rtmi_scene* sc) {
   }
   (void)hipFree(sc->d_objects); (void)hipFree(sc->d_lights); (void)hipFree(sc->d_materials);
   (void)hipFree(sc->d_tris); (void)hipFree(sc->d_planes); (void)hipFree(sc->d_tri_owner);
-  (void)hipFree(sc->d_gsph); (void)hipFree(sc->d_gst2); (void)hipFree(sc->d_run_start);
+  (void)hipFree(sc->d_trec); (void)hipFree(sc->d_gst2);
   (void)hipFree(sc->d_hit_id); (void)hipFree(sc->d_tri_hit); (void)hipFree(sc->d_q_child);
   (void)hipFree(sc->d_q_shade); (void)hipFree(sc->d_q_top); (void)hipFree(sc->d_rgb);
   (void)hipFree(sc->d_dirs); (void)hipFree(sc->d_tval); (void)hipFree(sc->d_best_pos); (void)hipFree(sc->d_cand); (void)hipFree(sc->d_tabs); (void)hipFree(sc->d_sargs); (void)hipFree(sc->d_genf);
@@ -1876,20 +1947,22 @@ static int32_t scene_create_impl(const rtmi_scene_desc* desc, int32_t device, rt
     }
     r_o1 *= 1.01;
     if (!std::isfinite(r_o1)) r_o1 = 0.0;  // the filter then degrades to "always nominate" via its own checks
-    std::vector<int> run_start((size_t)desc->n_objects, 0);
-    int ord = 0;
-    for (int64_t k = 0; k < desc->n_objects; ++k)
-      if (desc->objects[k].kind == RTMI_TRIANGLES) { run_start[k] = ord; ord += (int)desc->objects[k].count; }
-    if ((rc = upload((void**)&sc->d_run_start, run_start.data(), sizeof(int) * run_start.size()))) return rc;
     const size_t nt = top.size();
-    const size_t sph_floats = 16 * ((nt + GSPH_BATCH - 1) / GSPH_BATCH + 1);
-    HIP_TRY(hipMalloc(&sc->d_gsph, sizeof(float) * sph_floats));
-    HIP_TRY(hipMemset(sc->d_gsph, 0, sizeof(float) * sph_floats));  // padding triangles: T + 0 - |c|^2.. see below
     HIP_TRY(hipMalloc(&sc->d_gst2, sizeof(float) * GST2_FLOATS * nt));
     hipLaunchKernelGGL(k_pack_general, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, sc->stream, sc->d_tris,
-                       sc->groups[0].d_group, (int)nt, rtx::mk(c0[0], c0[1], c0[2]), r_o1, sc->d_gsph, sc->d_gst2);
+                       sc->groups[0].d_group, (int)nt, rtx::mk(c0[0], c0[1], c0[2]), r_o1, sc->d_gst2);
     HIP_TRY(hipGetLastError());
+    // bounding-sphere tree over the slot order of group 0
+    std::vector<float> trec;
+    tree_sphere_records(desc->triangles, sc->groups[0].tree_host, c0, r_o1, &trec);
+    if ((rc = upload((void**)&sc->d_trec, trec.data(), sizeof(float) * trec.size()))) return rc;
+    const TreeDev& td = sc->groups[0].tree;
+    sc->top_args.ltop = td.ltop;
+    sc->top_args.n_root = td.n_root;
+    sc->top_args.n_slots = td.n_slots;
+    for (int l = 0; l < TREE_MAX_LEVELS; ++l) sc->top_args.off[l] = td.rec_off[l];
   }
+  for (auto& g : sc->groups) g.tree_host = TreeHost();  // host copies are not needed any more
   HIP_TRY(hipMalloc(&sc->d_cnt, sizeof(DevCounters)));
   HIP_TRY(hipMalloc(&sc->d_genf, sizeof(float4) * std::max(1, n_sphere_like)));
   HIP_TRY(hipHostMalloc((void**)&sc->h_cnt, sizeof(DevCounters), hipHostMallocDefault));
@@ -1906,10 +1979,8 @@ static int32_t scene_create_impl(const rtmi_scene_desc* desc, int32_t device, rt
   sc->dev.n_lights = desc->n_lights;
   sc->dev.n_sphere_like = n_sphere_like;
   sc->dev.n_top_tris = (long long)top.size();
-  sc->dev.gsph = sc->d_gsph;
-  sc->dev.gst2 = sc->d_gst2;
   sc->dev.top_group = sc->groups[0].d_group;
-  sc->dev.run_start = sc->d_run_start;
+  sc->dev.tri_owner = sc->d_tri_owner;
   for (int a = 0; a < 3; ++a) sc->dev.c0[a] = c0[a];
   return RTMI_OK;
 }
@@ -2272,7 +2343,8 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
           hipLaunchKernelGGL(k_search_finish, dim3(grid), dim3(256), 0, st, sc->d_sargs + gi, par);
         else
           hipLaunchKernelGGL(has_top_runs ? k_shade_candidates<true> : k_shade_candidates<false>, dim3(sc->exact_grid), dim3(256),
-                             0, st, shc, sc->dev, sc->d_sargs + gi, sc->d_rgb, par);
+                             0, st, shc, sc->dev, sc->top_args, (const f2*)sc->d_trec, (const float*)sc->d_gst2,
+                             (const int*)sc->groups[0].d_slot_pos, sc->d_sargs + gi, sc->d_rgb, par);
       } else {
         hipLaunchKernelGGL(scan_kernel, dim3(search_grid), dim3(256), 0, st, sc->d_sargs + gi, (const f2*)g.d_cone);
         HIP_TRY(hipEventRecord(ev[1], st));
@@ -2292,7 +2364,8 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
     // lists nothing else that can be shaded (no sphere or light object, no top-level triangles)
     if (!(use_tree && !has_top_runs && sc->n_plain_shadeable == 0)) {
       if (b0 == 0) HIP_TRY(hipEventRecord(sc->ev_c, st));  // timed for the first batch only (frames are one batch as a rule)
-      hipLaunchKernelGGL(has_top_runs ? k_shade<true> : k_shade<false>, dim3(std::min(grid, 4 * sc->exact_grid)), dim3(256), 0, st, shc, sc->dev, sc->d_dirs, sc->d_tval, sc->d_q_shade, &sc->d_cnt->q_shade,
+      hipLaunchKernelGGL(has_top_runs ? k_shade<true> : k_shade<false>, dim3(std::min(grid, 4 * sc->exact_grid)), dim3(256), 0, st, shc, sc->dev, sc->top_args, (const f2*)sc->d_trec,
+                         (const float*)sc->d_gst2, (const int*)sc->groups[0].d_slot_pos, sc->d_dirs, sc->d_tval, sc->d_q_shade, &sc->d_cnt->q_shade,
                          sc->d_hit_id, sc->d_rgb, sc->d_cnt);
       if (b0 == 0) HIP_TRY(hipEventRecord(sc->ev_d, st));
       shade_queue_launched = true;

@@ -19,8 +19,9 @@
 //     and lie within a few pixels of each other): one record of eight sibling cones is
 //     fetched through scalar loads and evaluated with packed FP32 FMAs exactly like a batch of
 //     the list scan; a child is entered if ANY ray of the wave passes its cone.  At a leaf the
-//     nominated (ray, triangle) pairs go through the edge test and then the FP64 decision
-//     (rtx::tri_hit), and a hit replaces the ray's current one if its list position is lower.
+//     nominated (ray, triangle) pairs go through the edge test; the survivors are the
+//     candidates that k_search_exact decides in FP64 (rtx::tri_hit), keeping the lowest list
+//     position per ray.
 //
 // A ray that truly hits a triangle has its direction inside that triangle's cone, hence inside
 // the cone of every ancestor, so it reaches the leaf: the filter never loses a hit.
@@ -142,6 +143,92 @@ static void tree_build_host(const rtmi_triangle* tris, const std::vector<int>& i
   }
   th->n_records = rec;
   th->n_node_buf = std::max<size_t>(nodes, 1);
+}
+
+// Bounding-sphere records over the same slot order, for rays of ANY origin (reflection and shadow
+// rays against the top-level runs).  Built once per scene on the host in FP64.  A record holds eight
+// sibling spheres as 4 pairs x (cx, cy, cz, nK) x (child a, child b): a ray's LINE comes within rho
+// of c iff (d.(c-o))^2 + rho^2 - |c-o|^2 >= 0, evaluated as T + nK >= 0 with A = d.c - d.o,
+// T = A*A + (2 c.o - |o|^2) and nK = rho^2 + delta - |c|^2; delta = 64*2^-24*(|c|_1 + r_o1)^2 exceeds the
+// FP32 evaluation error of T (about 40*2^-24*(|c|_1+|o|_1)^2).  Coordinates are relative to c0; r_o1
+// bounds |o - c0|_1 over every possible ray origin.  Absent children get nK = -3e38 (never pass),
+// non-finite ones +3e38 (always pass).
+static void tree_sphere_records(const rtmi_triangle* tris, const TreeHost& th, const double c0[3], double r_o1,
+                                std::vector<float>* out) {
+  struct Sph { double c[3]; double r; bool valid; };
+  const TreeDev& d = th.dev;
+  out->assign(th.n_records * REC_DWORDS, 0.0f);
+  // nodes that do not exist (the tail of a level's last record) must never pass: an all-zero entry
+  // WOULD pass for a ray whose line runs through c0
+  for (size_t r = 0; r < th.n_records; ++r)
+    for (int pr = 0; pr < 4; ++pr) {
+      (*out)[r * REC_DWORDS + pr * 8 + 6] = -3.0e38f;
+      (*out)[r * REC_DWORDS + pr * 8 + 7] = -3.0e38f;
+    }
+  auto store = [&](int level, int j, const Sph& sp) {
+    float* dst = out->data() + (size_t)(d.rec_off[level] + (j >> 3)) * REC_DWORDS + ((j & 7) >> 1) * 8 + (j & 1);
+    float fx = 0.f, fy = 0.f, fz = 0.f, fk = -3.0e38f;
+    if (sp.valid) {
+      const double eps32 = 5.9604644775390625e-08;  // 2^-24
+      double s1 = fabs(sp.c[0]) + fabs(sp.c[1]) + fabs(sp.c[2]) + r_o1;
+      double nK = sp.r * sp.r * (1.0 + 1e-6) + 64.0 * eps32 * s1 * s1 - (sp.c[0] * sp.c[0] + sp.c[1] * sp.c[1] + sp.c[2] * sp.c[2]);
+      fx = (float)sp.c[0]; fy = (float)sp.c[1]; fz = (float)sp.c[2]; fk = (float)nK;
+      if (!std::isfinite(fx) || !std::isfinite(fy) || !std::isfinite(fz) || !std::isfinite(fk)) { fx = fy = fz = 0.f; fk = 3.0e38f; }
+    }
+    dst[0] = fx; dst[2] = fy; dst[4] = fz; dst[6] = fk;
+  };
+  std::vector<Sph> cur((size_t)d.n_nodes[0]);
+  for (int p = 0; p < d.n_nodes[0]; ++p) {
+    Sph sp{};
+    const int ti = th.slot_tri[p];
+    sp.valid = ti >= 0;
+    if (sp.valid) {
+      double v[3][3];
+      for (int q = 0; q < 3; ++q) for (int a = 0; a < 3; ++a) v[q][a] = tris[ti].v[q][a] - c0[a];
+      for (int a = 0; a < 3; ++a) sp.c[a] = (v[0][a] + v[1][a] + v[2][a]) / 3.0;
+      double r2 = 0;
+      for (int q = 0; q < 3; ++q) {
+        double e = 0;
+        for (int a = 0; a < 3; ++a) e += (v[q][a] - sp.c[a]) * (v[q][a] - sp.c[a]);
+        r2 = std::max(r2, e);
+      }
+      sp.r = sqrt(r2) * (1.0 + 1e-12);
+      if (!(sp.r >= 0)) sp.r = NAN;  // NaN vertices: stored as "always pass"
+    }
+    store(0, p, sp);
+    cur[p] = sp;
+  }
+  for (int L = 1; L <= d.ltop; ++L) {
+    std::vector<Sph> next((size_t)d.n_nodes[L]);
+    for (int j = 0; j < d.n_nodes[L]; ++j) {
+      Sph sp{};
+      int nv = 0;
+      for (int k = 0; k < 8; ++k) {
+        int ch = j * 8 + k;
+        if (ch >= d.n_nodes[L - 1] || !cur[ch].valid) continue;
+        for (int a = 0; a < 3; ++a) sp.c[a] += cur[ch].c[a];
+        ++nv;
+      }
+      sp.valid = nv > 0;
+      if (sp.valid) {
+        for (int a = 0; a < 3; ++a) sp.c[a] /= nv;
+        bool bad = false;
+        for (int k = 0; k < 8; ++k) {
+          int ch = j * 8 + k;
+          if (ch >= d.n_nodes[L - 1] || !cur[ch].valid) continue;
+          double e = 0;
+          for (int a = 0; a < 3; ++a) e += (cur[ch].c[a] - sp.c[a]) * (cur[ch].c[a] - sp.c[a]);
+          double reach = (sqrt(e) + cur[ch].r) * (1.0 + 1e-12);
+          if (reach != reach) bad = true;
+          else if (reach > sp.r) sp.r = reach;
+        }
+        if (bad) sp.r = NAN;  // stored as "always pass"
+      }
+      store(L, j, sp);
+      next[j] = sp;
+    }
+    cur.swap(next);
+  }
 }
 
 // ---------------------------------------------------------------------------------------

@@ -92,6 +92,31 @@ def test_toplevel_mesh_5120_triangles_secondary_ray_filter(oracle_mod, rt):
         assert o["rays_shadow"] > 0 and g["tri_tests"] > g["tri_tests_primary_kernel"] > 0
 
 
+def test_toplevel_mesh_full_hd_secondary_rays_through_the_sphere_tree(oracle_mod, rt):
+    """Form T at 1920x1080, 4 spp: 10 M secondary rays walk the bounding-sphere tree of the top-level
+    triangles (among them rays whose line runs through the tree's coordinate centre, which an
+    all-zero record entry would let through).  Cone tree and list scan must give the same frame, and
+    two windows are checked against the oracle."""
+    import copy
+    data = scenes.mesh_scene(4, "T", 3)
+    cam = scenes.make_camera(**scenes.MESH_CAMERA)
+    params = scenes.make_params(1920, 1080, 0.5)
+    sc = rt.Scene(data)
+    full, fhit, cnt = sc.render(cam, params)
+    p2 = copy.copy(params)
+    p2.search = _abi.RTMI_SEARCH_LIST_SCAN
+    scan, shit, cnt2 = sc.render(cam, p2)
+    sc.close()
+    assert (full == scan).all() and (fhit == shit).all()
+    for k in ("samples", "rays_reflection", "rays_shadow", "primary_hits"):
+        assert cnt[k] == cnt2[k], k
+    for win in ((940, 530, 972, 546), (655, 310, 687, 326)):
+        x0, y0, x1, y1 = win
+        o_rgba, o_hit, _ = oracle_mod.render(data, cam, scenes.make_params(1920, 1080, 0.5, window=win), threads=16)
+        assert (o_hit[y0:y1, x0:x1] == fhit[y0:y1, x0:x1]).all()
+        assert (o_rgba[y0:y1, x0:x1] == full[y0:y1, x0:x1]).all()
+
+
 def test_toplevel_mesh_far_from_origin(oracle_mod, rt):
     """Form T with coordinates of order 1e5 (FP32 filter margins scale with the scene extent)."""
     v, f = scenes.displaced_icosphere(2)
