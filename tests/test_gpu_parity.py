@@ -68,7 +68,7 @@ def test_reference_two_sphere_scene_1000x1000(oracle_mod, rt):
     assert o["samples"] == 998001
 
 
-@pytest.mark.parametrize("sub", [1.0, 0.5, 0.25, 0.3])
+@pytest.mark.parametrize("sub", [1.0, 0.5, 0.25, 0.3, 0.4, 0.15])  # 1, 4, 16, 16, 9 and 49 samples per pixel
 def test_bounded_mesh_supersampling(oracle_mod, rt, sub):
     data = scenes.mesh_scene(3, "B", 3, bounding_sphere=rt.bounding_sphere)
     cam = scenes.make_camera(**scenes.MESH_CAMERA)
@@ -285,6 +285,25 @@ def test_deep_stack_of_overlapping_triangles(oracle_mod, rt):
     cam = scenes.make_camera(**scenes.MESH_CAMERA)
     o, g = assert_parity(oracle_mod, rt, data, cam, scenes.make_params(64, 64, 0.5))
     assert o["primary_hits"] > 0
+
+
+def test_tiles_that_are_not_multiples_of_the_pixel_blocks(rt):
+    """Tile edges that do not fall on 8-pixel block borders take the per-pixel ownership test: the
+    ranks' frames still partition the full frame."""
+    data = scenes.mesh_scene(3, "B", 2, bounding_sphere=rt.bounding_sphere)
+    cam = scenes.make_camera(**scenes.MESH_CAMERA)
+    params = scenes.make_params(301, 203, 0.5)
+    sc = rt.Scene(data)
+    full, _, _ = sc.render(cam, params, want_hit_ids=False)
+    for tile in (20, 7):
+        acc = np.zeros_like(full, dtype=np.int32)
+        for r in range(3):
+            fr, _, _ = sc.render(cam, sharding.tile_params(params, r, 3, tile_size=tile), want_hit_ids=False)
+            mask = sharding.owned_pixel_mask(301, 203, r, 3, tile_size=tile)
+            assert (fr[~mask] == 0).all()
+            acc += fr
+        assert (acc == full).all()
+    sc.close()
 
 
 def test_render_errors(rt):
