@@ -176,6 +176,14 @@ int32_t rtmi_device_count(void);
 int32_t rtmi_bounding_sphere(const rtmi_triangle* triangles, int64_t n, double center[3],
                              double* radius);
 
+/* The spatial order in which the cone tree stores a triangle list: slot_pos[slot] = list position,
+ * -1 for the padding slots of the last leaf; consecutive runs of 8 slots are the tree's leaves, runs
+ * of 8^k leaves its inner nodes.  *n_slots receives the slot count (n rounded up to a multiple of 8,
+ * at least 8); slot_pos may be NULL to query it.  Host arithmetic only.  No counterpart in the
+ * reference, whose only acceleration is Sphere(boundingObjects:) (Renderables.swift:215-246). */
+int32_t rtmi_tree_slot_order(const rtmi_triangle* triangles, int64_t n, int32_t* slot_pos,
+                             int64_t capacity, int64_t* n_slots);
+
 /* Flatten and upload a scene to `device` (what the reference holds as the `objects`,
  * `lights` arrays and material values at ViewController.swift:155-167).  The descriptor
  * and everything it points to may be freed after the call returns. */

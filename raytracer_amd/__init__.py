@@ -74,6 +74,8 @@ def lib():
         for name in ("rtmi_write_ppm", "rtmi_write_png"):
             getattr(L, name).restype = C.c_int32
             getattr(L, name).argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]
+        L.rtmi_tree_slot_order.restype = C.c_int32
+        L.rtmi_tree_slot_order.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
         if L.rtmi_abi_version() != _abi.RTMI_ABI_VERSION:
             raise ImportError("librtmi.so ABI version does not match raytracer_amd/_abi.py")
         _lib = L
@@ -121,6 +123,16 @@ def load_obj(obj_path, mtl_path=None):
         return tris, mats, names, L.rtmi_obj_vertex_count(h)
     finally:
         lib().rtmi_obj_free(h)
+
+
+def tree_slot_order(triangles: np.ndarray) -> np.ndarray:
+    """slot -> list position (-1 = padding) of the cone tree's spatial order (rtmi_tree_slot_order)."""
+    tri = np.ascontiguousarray(triangles)
+    n = C.c_int64()
+    _check(lib().rtmi_tree_slot_order(tri.ctypes.data, len(tri), None, 0, C.byref(n)), "rtmi_tree_slot_order")
+    out = np.empty(n.value, np.int32)
+    _check(lib().rtmi_tree_slot_order(tri.ctypes.data, len(tri), out.ctypes.data, len(out), C.byref(n)), "rtmi_tree_slot_order")
+    return out
 
 
 def write_image(path, rgba: np.ndarray):

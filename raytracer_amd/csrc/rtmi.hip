@@ -3,16 +3,22 @@
 // Replaces the reference's raytraceWorld / raytracePixels / calculateLighting call tree
 // (RayTraceUI/RayTracingFunctions.swift:59-114, :145-271) with a staged GPU pipeline:
 //
-//   k_pack_primary   per frame: triangles -> FP32 filter operands relative to the camera
-//   k_gen            per sample: ray generation + top-level sphere/light tests
-//   k_search_primary per (ray, triangle): packed-FP32 conservative filter, FP64 exact
-//                    re-test of every nominee; lowest list position wins
-//   k_shade          per hit sample: calculateLighting in FP64
-//   k_resolve        per pixel: sample average, x255 truncation, RGBA8 store
+//   k_frame_tables, k_pack_tree   per camera: sample tables; cones of the triangles and of the
+//                                 tree nodes above them (rtmi_tree.h)
+//   k_gen               per sample: FP32 pre-test, ray generation, sphere/light tests (FP64)
+//   k_search_tree       per wave of 256 rays: one walk of the cone tree, packed-FP32 cone and
+//                       edge tests; emits (sample, list position) candidates
+//   k_search_exact      per candidate: the reference's triangle test in FP64; lowest list
+//                       position per ray
+//   k_shade_candidates  per candidate: the ray's intersection is shaded (calculateLighting, FP64)
+//   k_shade             per queued hit (spheres, lights, top-level triangles): the same shading
+//   k_resolve           per pixel: sample average, x255 truncation, RGBA8 store
 //
-// The hot kernel is k_search_primary.  One lane owns R rays; triangle operands are
-// wave-uniform and arrive through scalar loads into SGPRs, two triangles per
-// v_pk_fma_f32; no LDS, no MFMA, no cross-lane traffic in the steady state.
+// RTMI_SEARCH_LIST_SCAN replaces the three search kernels by k_search_primary (k_pack_flags /
+// _scan / _write): every front-facing triangle in list order until the ray's first hit, one lane
+// per 4 rays, triangle operands wave-uniform in SGPRs, two triangles per v_pk_fma_f32.
+// Scenes that list triangles at top level add k_search_finish / k_resolve_top (primary rays) and
+// walk a bounding-sphere tree for their reflection and shadow rays (top_tree_trace).
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see Makefile).
 #include <hip/hip_runtime.h>
@@ -1807,6 +1813,22 @@ extern "C" int32_t rtmi_bounding_sphere(const rtmi_triangle* tris, int64_t n, do
   for (int a = 0; a < 3; ++a) ext[a] = fabs(hi[a] - lo[a]);
   *radius = std::max(ext[0], std::max(ext[1], ext[2])) / 2;
   for (int a = 0; a < 3; ++a) center[a] = hi[a] - (ext[a] / 2);
+  return RTMI_OK;
+}
+
+// The spatial slot order the cone tree gives a triangle list (host arithmetic only).
+extern "C" int32_t rtmi_tree_slot_order(const rtmi_triangle* tris, int64_t n, int32_t* slot_pos, int64_t capacity,
+                                        int64_t* n_slots) {
+  if ((!tris && n > 0) || n < 0 || n > 0x7ffffff0LL || !n_slots) return RTMI_ERR_INVALID_ARGUMENT;
+  std::vector<int> idx((size_t)n);
+  for (int64_t i = 0; i < n; ++i) idx[(size_t)i] = (int)i;
+  TreeHost th;
+  tree_build_host(tris, idx, &th);
+  *n_slots = (int64_t)th.slot_pos.size();
+  if (slot_pos) {
+    if (capacity < *n_slots) return RTMI_ERR_INVALID_ARGUMENT;
+    std::copy(th.slot_pos.begin(), th.slot_pos.end(), slot_pos);
+  }
   return RTMI_OK;
 }
 
