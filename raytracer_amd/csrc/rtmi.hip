@@ -823,6 +823,7 @@ struct SearchArgs {
   double cam[3];
   int mode, obj_filter;
   const int* group;  // list position -> triangle index (the tree search keeps positions)
+  int n_group;       // triangles in the group (entries of `group`)
   int* best_pos;     // per sample: lowest list position hit so far (tree search)
   int2* cand;        // (sample, triangle slot) candidates of the tree search
   int cand_cap;
@@ -1297,7 +1298,9 @@ k_search_finish(const SearchArgs* __restrict__ ap, int parity) {
   const int s = ap->queue[q];
   int ti = -1;
   const int pos = ap->best_pos[s];
-  if (pos != 0x7fffffff) {
+  // After a candidate-list overflow the frame is rendered again; all this launch must do then is
+  // leave valid indices behind.  The range check keeps any unexpected value from becoming an address.
+  if (!ap->cnt->overflow && (unsigned)pos < (unsigned)ap->n_group) {
     ti = ap->group[pos];
     const double* dp = ap->dirs + (size_t)s * 3;
     const double tv = rtx::tri_t(ap->planes[ti], rtx::ld3(ap->cam), rtx::mk(dp[0], dp[1], dp[2]));
@@ -1660,7 +1663,8 @@ struct rtmi_scene {
   double* d_dirs = nullptr;
   double* d_tval = nullptr;
   int* d_best_pos = nullptr;   // tree search: per sample, lowest list position hit
-  int2* d_cand = nullptr;      // tree search: candidate pairs, cap_samples entries
+  int2* d_cand = nullptr;      // tree search: candidate pairs, cap_cand entries in NSLOT lists
+  size_t cap_cand = 0;
   std::vector<SearchArgs> h_sargs;   // one argument block per triangle group
   SearchArgs* d_sargs = nullptr;
   double* d_tabs = nullptr;  // utab then vtab
@@ -2041,7 +2045,10 @@ static int32_t ensure_buffers(rtmi_scene* sc, size_t samples, size_t blocks) {
     HIP_TRY(hipMalloc(&sc->d_dirs, sizeof(double) * 3 * samples));
     HIP_TRY(hipMalloc(&sc->d_tval, sizeof(double) * samples));
     HIP_TRY(hipMalloc(&sc->d_best_pos, sizeof(int) * samples));
-    HIP_TRY(hipMalloc(&sc->d_cand, sizeof(int2) * samples));
+    // A closed mesh that fills the frame yields about one candidate per sample; twice that, plus a
+    // floor that keeps each of the NSLOT lists roomy when few waves share few lists (small frames).
+    sc->cap_cand = 2 * samples + (size_t)NSLOT * 16384;
+    HIP_TRY(hipMalloc(&sc->d_cand, sizeof(int2) * sc->cap_cand));
     sc->cap_samples = samples;
   }
   if (blocks > sc->cap_blocks) {
@@ -2306,7 +2313,8 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
     a.group = g.d_group;
     a.best_pos = sc->d_best_pos;
     a.cand = sc->d_cand;
-    a.cand_cap = (int)std::min<size_t>(sc->cap_samples, 0x7fffffff);
+    a.n_group = g.n;
+    a.cand_cap = (int)std::min<size_t>(sc->cap_cand, 0x7fffffff);
     a.tree = g.tree;
   }
   if (sc->sargs_uploaded.size() != sc->h_sargs.size() ||
