@@ -101,7 +101,8 @@ struct DevCounters {
   unsigned long long slot[NSLOT][C_NCOUNTERS];
   int q_child, q_shade, q_top;  // queue fill levels
   int overflow;                 // a candidate list of the tree search did not fit
-  int pad[4];
+  int bug;                      // nonzero: an index check failed (see checked()); the call reports an error
+  int pad[3];
   unsigned long long cand_total;  // candidates of all tree search launches of the frame
   // The tree search keeps NSLOT candidate lists (a wave appends to list `wave & 63`), each with its
   // fill level on a cache line of its own: returning atomics on ONE address complete at roughly
@@ -118,6 +119,7 @@ struct SceneDev {
   const rtmi_triangle* tris;
   const TriPlane* planes;
   int n_objects, n_lights, n_sphere_like;
+  int n_tris, n_samples;  // entries of tris/planes; entries of the per-sample arrays (for checked())
   long long n_top_tris;
   // general-origin filter of the top-level triangle runs (secondary rays), built once per scene
   const int* top_group;  // top-level ordinal -> triangle index
@@ -192,6 +194,17 @@ __global__ void k_frame_tables(FrameConst fc, double* utab, double* vtab, float*
     vtab[(size_t)j * 3 + 0] = r.x; vtab[(size_t)j * 3 + 1] = r.y; vtab[(size_t)j * 3 + 2] = r.z;
     vtab_f[(size_t)j * 3 + 0] = (float)r.x; vtab_f[(size_t)j * 3 + 1] = (float)r.y; vtab_f[(size_t)j * 3 + 2] = (float)r.z;
   }
+}
+
+// An index that was READ FROM DEVICE MEMORY and is about to become an address.  Only a defect
+// elsewhere can put it out of range; if one does, the index is replaced by 0 and the call ends with
+// an error (DevCounters::bug names the check) instead of a memory fault on the GPU.
+__device__ __forceinline__ int checked(int v, int n, DevCounters* cnt, int code) {
+  if (__builtin_expect((unsigned)v >= (unsigned)n, 0)) {
+    cnt->bug = code;
+    return 0;
+  }
+  return v;
 }
 
 // Sum v over the wave and add it to this wave's stripe of counter `idx`.
@@ -456,20 +469,20 @@ struct TopTreeRef {
   const f2* rec;        // sphere records, all levels (tree_sphere_records)
   const float* gst2;    // per top-level ordinal: plane and edge operands (k_pack_general)
   const int* slot_pos;  // slot -> top-level ordinal (= position among the top-level triangles)
-  int ltop, n_root, n_slots;
+  int ltop, n_root, n_slots, n_records;
   int off[TREE_MAX_LEVELS];
 };
 
 // The scalar part of TopTreeRef, passed to the kernels by value.
 struct TopTreeArgs {
-  int ltop, n_root, n_slots;
+  int ltop, n_root, n_slots, n_records;
   int off[TREE_MAX_LEVELS];
 };
 
 __device__ inline TopTreeRef make_top_tree(const TopTreeArgs& a, const f2* rec, const float* gst2, const int* slot_pos) {
   TopTreeRef t;
   t.rec = rec; t.gst2 = gst2; t.slot_pos = slot_pos;
-  t.ltop = a.ltop; t.n_root = a.n_root; t.n_slots = a.n_slots;
+  t.ltop = a.ltop; t.n_root = a.n_root; t.n_slots = a.n_slots; t.n_records = a.n_records;
 #pragma unroll
   for (int l = 0; l < TREE_MAX_LEVELS; ++l) t.off[l] = a.off[l];
   return t;
@@ -507,7 +520,7 @@ __device__ inline int top_tree_trace(const SceneDev& sc, const TopTreeRef& T, d3
          : lvl == 6 ? T.off[6] : T.off[7];
   };
   auto eval = [&](int lvl, int ri) -> unsigned {
-    const f2* rp = T.rec + (size_t)(level_off(lvl) + ri) * (REC_DWORDS / 2);
+    const f2* rp = T.rec + (size_t)min(level_off(lvl) + ri, T.n_records - 1) * (REC_DWORDS / 2);  // the clamp never binds
     const bool live = !any_only || best == 0x7fffffff;
     unsigned mask = 0;
 #pragma unroll
@@ -519,7 +532,7 @@ __device__ inline int top_tree_trace(const SceneDev& sc, const TopTreeRef& T, d3
     return (unsigned)__builtin_amdgcn_readfirstlane((int)mask);
   };
   auto leaf = [&](int ri) {
-    if (ri * 8 >= T.n_slots) return;  // cannot happen (absent nodes never pass); keeps a bad record from becoming a bad address
+    if ((unsigned)(ri * 8) >= (unsigned)T.n_slots) return;  // cannot happen (absent nodes never pass); keeps a bad record from becoming a bad address
     const f2* rp = T.rec + (size_t)(T.off[0] + ri) * (REC_DWORDS / 2);
     const bool live = !any_only || best == 0x7fffffff;
     if (live) ++leaf_visits;
@@ -532,7 +545,7 @@ __device__ inline int top_tree_trace(const SceneDev& sc, const TopTreeRef& T, d3
         bool cand = live && !(u < 0.0f);
         if (!__any(cand)) continue;
         const int g = T.slot_pos[ri * 8 + pr * 2 + h];  // top-level ordinal
-        if (g < 0) continue;                            // padding slot (its sphere passes nothing; belt and braces)
+        if ((unsigned)g >= (unsigned)sc.n_top_tris) continue;  // padding slot (its sphere passes nothing; belt and braces)
         cand = cand && (any_only ? best == 0x7fffffff : g < best);  // a later list position cannot replace the hit
         if (!__any(cand)) continue;
         const float* s2 = T.gst2 + (size_t)g * GST2_FLOATS;
@@ -552,7 +565,7 @@ __device__ inline int top_tree_trace(const SceneDev& sc, const TopTreeRef& T, d3
         }
         if (!__any(cand)) continue;
         if (cand) {
-          const int ti = sc.top_group[g];
+          const int ti = min(max(sc.top_group[g], 0), sc.n_tris - 1);  // the clamps never bind
           const rtmi_triangle& tr = sc.tris[ti];
           double t;
           d3 P;
@@ -651,7 +664,7 @@ __device__ inline bool trace_top_secondary(const SceneDev& sc, const TopTreeRef&
       const int g = top_tree_trace(sc, tt, o, d, !want_first, &t, &P, n_tests);
       if (g >= 0) {
         anb = true;
-        const int ti = sc.top_group[g];
+        const int ti = min(max(sc.top_group[g], 0), sc.n_tris - 1);
         if (want_first && sc.tri_owner[ti] < first_obj) {
           found = true;
           const TriPlane pl = sc.planes[ti];
@@ -763,15 +776,16 @@ k_resolve_top(SceneDev sc, const int* __restrict__ q_top, const int* __restrict_
   bool to_child = false, to_shade = false;
   int s = -1;
   if (q < *nq_ptr) {
-    s = q_top[q];
+    s = checked(q_top[q], sc.n_samples, cnt, 14);
     int id = hit_id[s];
     int th = tri_hit[q];
+    if (th >= 0) th = checked(th, sc.n_tris, cnt, 15);
     int obj = id <= -2 ? -2 - id : 0x7fffffff;
     if (th >= 0 && tri_owner[th] < obj) { id = th; obj = -1; }
     hit_id[s] = id;
     if (id >= 0) to_shade = true;
     else if (id <= -2) {
-      if (sc.objects[obj].kind == RTMI_BOUNDING_SPHERE) to_child = true; else to_shade = true;
+      if (sc.objects[checked(obj, sc.n_objects, cnt, 16)].kind == RTMI_BOUNDING_SPHERE) to_child = true; else to_shade = true;
     }
   }
   block_append(&cnt->q_child, q_child, to_child, s);
@@ -824,6 +838,7 @@ struct SearchArgs {
   int mode, obj_filter;
   const int* group;  // list position -> triangle index (the tree search keeps positions)
   int n_group;       // triangles in the group (entries of `group`)
+  int n_samples, n_tris, n_records;  // entries of the per-sample arrays, of tris/planes, of the tree's records
   int* best_pos;     // per sample: lowest list position hit so far (tree search)
   int2* cand;        // (sample, triangle slot) candidates of the tree search
   int cand_cap;
@@ -845,7 +860,7 @@ __device__ __forceinline__ void search_prologue(const SearchArgs* ap, int base, 
   for (int r = 0; r < R; ++r) {
     int q = base + r * 64 + lane;
     bool valid = q < nq;
-    sid[r] = valid ? queue[q] : -1;
+    sid[r] = valid ? checked(queue[q], ap->n_samples, ap->cnt, 1) : -1;
     if (valid && mode == 0 && hit_id[sid[r]] != -2 - obj_filter) sid[r] = -1;
     dx[r] = dy[r] = dz[r] = qnan;
     if (sid[r] >= 0) {
@@ -986,7 +1001,7 @@ k_search_primary(const SearchArgs* __restrict__ ap, const f2* __restrict__ cone)
           // one copy of the double-precision code keeps the kernel's register count (and with it
           // the occupancy of the steady-state loop) low; r is wave-uniform, so the selects below
           // are scalar branches.
-          const int ti = a2->packed_tri[g];
+          const int ti = checked(a2->packed_tri[g], a2->n_tris, a2->cnt, 2);
 #pragma nounroll
           for (int r = 0; r < R; ++r) {
             const bool mine = (nom >> r) & 1u;
@@ -1147,7 +1162,12 @@ k_search_tree(const SearchArgs* __restrict__ ap, const f2* __restrict__ rec, con
   // Level-0 record `ri`: the triangle cones of slots 8*ri..8*ri+7 against every ray of the lane.
   // A triangle that no ray of the wave passes costs three maxima and a vote; for the others the
   // edge test follows at once, and what remains is a candidate.
+  const int n_slots = ap->tree.n_slots, n_records = ap->n_records;
   auto leaf = [&](int ri) {
+    if ((unsigned)(ri * 8) >= (unsigned)n_slots) {  // only a defective record can lead here
+      ap->cnt->bug = 3;
+      return;
+    }
     ++n_leaf_rec;
     const f2* rp = rec + (size_t)(o0 + ri) * (REC_DWORDS / 2);
     f2 cur[12];
@@ -1173,7 +1193,7 @@ k_search_tree(const SearchArgs* __restrict__ ap, const f2* __restrict__ rec, con
         if (!__any(mq >= 1.0f) && !((always >> jj) & 1u)) continue;
         const float* m = edge + jj * EDGE_FLOATS;
         const float m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3], m4 = m[4], m5 = m[5], m6 = m[6], m7 = m[7], m8 = m[8];
-        const int pos = slot_pos[ri * 8 + jj];  // the triangle's position in the group's list order
+        const int pos = checked(slot_pos[ri * 8 + jj], ap->n_group, ap->cnt, 4);  // the triangle's position in the group's list order
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           const float qv = h ? q[r].y : q[r].x;
@@ -1205,7 +1225,7 @@ k_search_tree(const SearchArgs* __restrict__ ap, const f2* __restrict__ rec, con
       int lvl = ltop, ri = t;
       unsigned long long masks;
       {
-        unsigned m = tree_eval<R>(rec + (size_t)(level_off(lvl) + ri) * (REC_DWORDS / 2), dx, dy, dz);
+        unsigned m = tree_eval<R>(rec + (size_t)checked(level_off(lvl) + ri, n_records, ap->cnt, 5) * (REC_DWORDS / 2), dx, dy, dz);
         masks = (unsigned long long)m << (8 * lvl);
         ++n_node_rec;
       }
@@ -1225,7 +1245,7 @@ k_search_tree(const SearchArgs* __restrict__ ap, const f2* __restrict__ rec, con
         } else {
           --lvl;
           ri = child;
-          unsigned m = tree_eval<R>(rec + (size_t)(level_off(lvl) + ri) * (REC_DWORDS / 2), dx, dy, dz);
+          unsigned m = tree_eval<R>(rec + (size_t)checked(level_off(lvl) + ri, n_records, ap->cnt, 5) * (REC_DWORDS / 2), dx, dy, dz);
           masks |= (unsigned long long)m << (8 * lvl);
           ++n_node_rec;
         }
@@ -1254,7 +1274,7 @@ k_search_exact(const SearchArgs* __restrict__ ap, int parity) {
   if (!cnt->overflow) {  // after an overflow the lists are incomplete and the frame is rendered again
     const int list = blockIdx.x & (NSLOT - 1), part = blockIdx.x / NSLOT, parts = gridDim.x / NSLOT;
     const int list_cap = ap->cand_cap / NSLOT;
-    const int n = cnt->cand_n[parity][list][0];
+    const int n = min(cnt->cand_n[parity][list][0], list_cap);
     const int2* cand = ap->cand + (size_t)list * list_cap;
     const double* dirs = ap->dirs;
     const d3 o = rtx::ld3(ap->cam);
@@ -1264,12 +1284,20 @@ k_search_exact(const SearchArgs* __restrict__ ap, int parity) {
     const int stride = parts * blockDim.x;
     const int* group = ap->group;
     int i = part * blockDim.x + threadIdx.x;
-    int2 c = i < n ? cand[i] : make_int2(0, 0);
-    int ti = i < n ? group[c.y] : 0;
+    DevCounters* wcnt = ap->cnt;
+    const int n_group = ap->n_group, n_samples = ap->n_samples, n_tris = ap->n_tris;
+    auto entry = [&](int k) {  // candidate k with both indices range-checked
+      int2 e = cand[k];
+      e.x = checked(e.x, n_samples, wcnt, 6);
+      e.y = checked(e.y, n_group, wcnt, 7);
+      return e;
+    };
+    int2 c = i < n ? entry(i) : make_int2(0, 0);
+    int ti = i < n ? checked(group[c.y], n_tris, wcnt, 8) : 0;
     while (i < n) {
       const int inext = i + stride;
-      const int2 cn = inext < n ? cand[inext] : c;
-      const int tin = group[cn.y];
+      const int2 cn = inext < n ? entry(inext) : c;
+      const int tin = checked(group[cn.y], n_tris, wcnt, 8);
       const int s = c.x, pos = c.y;
       const double* dp = dirs + (size_t)s * 3;
       const rtmi_triangle& tr = ap->tris[ti];
@@ -1295,13 +1323,13 @@ k_search_finish(const SearchArgs* __restrict__ ap, int parity) {
   search_lists_retire(ap->cnt, parity);
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= nq) return;
-  const int s = ap->queue[q];
+  const int s = checked(ap->queue[q], ap->n_samples, ap->cnt, 12);
   int ti = -1;
   const int pos = ap->best_pos[s];
   // After a candidate-list overflow the frame is rendered again; all this launch must do then is
   // leave valid indices behind.  The range check keeps any unexpected value from becoming an address.
   if (!ap->cnt->overflow && (unsigned)pos < (unsigned)ap->n_group) {
-    ti = ap->group[pos];
+    ti = checked(ap->group[pos], ap->n_tris, ap->cnt, 13);
     const double* dp = ap->dirs + (size_t)s * 3;
     const double tv = rtx::tri_t(ap->planes[ti], rtx::ld3(ap->cam), rtx::mk(dp[0], dp[1], dp[2]));
     ap->tval[s] = tv;  // the hit point is origin + t*direction; shading rebuilds it
@@ -1513,9 +1541,12 @@ k_shade(ShadeConst fc, SceneDev sc, TopTreeArgs ta, const f2* __restrict__ trec,
   ShadeTally tl;
   const int nq = *nq_ptr;
   for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
-    int s = q_shade[q];
+    int s = checked(q_shade[q], sc.n_samples, cnt, 17);
     d3 d = rtx::mk(dirs[(size_t)s * 3 + 0], dirs[(size_t)s * 3 + 1], dirs[(size_t)s * 3 + 2]);
     int id = hit_id[s];
+    // a triangle index or -2 - object index, both about to be used as such
+    if (id >= 0) id = checked(id, sc.n_tris, cnt, 18);
+    else id = -2 - checked(-2 - id, sc.n_objects, cnt, 19);
     shade_sample<HAS_TOP>(fc, sc, tt, s, d, id, id >= 0 ? tval[s] : 0.0, rgb, &tl);
   }
   shade_tally_flush(cnt, tl);
@@ -1531,13 +1562,13 @@ template <bool HAS_TOP>
 __global__ void __launch_bounds__(256, HAS_TOP ? 2 : 4)
 k_shade_candidates(ShadeConst fc, SceneDev sc, TopTreeArgs ta, const f2* __restrict__ trec, const float* __restrict__ gst2,
                    const int* __restrict__ tslot_pos, const SearchArgs* __restrict__ ap, double* rgb, int par) {
-  const TopTreeRef tt = make_top_tree(ta, trec, gst2, tslot_pos);
   DevCounters* cnt = ap->cnt;
+  const TopTreeRef tt = make_top_tree(ta, trec, gst2, tslot_pos);
   ShadeTally tl;
   if (!cnt->overflow) {
     const int list = blockIdx.x & (NSLOT - 1), part = blockIdx.x / NSLOT, parts = gridDim.x / NSLOT;
     const int list_cap = ap->cand_cap / NSLOT;
-    const int n = cnt->cand_n[par][list][0];
+    const int n = min(cnt->cand_n[par][list][0], list_cap);
     const int2* cand = ap->cand + (size_t)list * list_cap;
     const double* dirs = ap->dirs;
     // as in k_search_exact: the next step's entry and what hangs on it are fetched one step ahead
@@ -1545,13 +1576,20 @@ k_shade_candidates(ShadeConst fc, SceneDev sc, TopTreeArgs ta, const f2* __restr
     const int* group = ap->group;
     const int* best_pos = ap->best_pos;
     int i = part * blockDim.x + threadIdx.x;
-    int2 c = i < n ? cand[i] : make_int2(0, 0);
-    int ti = i < n ? group[c.y] : 0;
+    const int n_group = ap->n_group, n_samples = ap->n_samples, n_tris = ap->n_tris;
+    auto entry = [&](int k) {  // candidate k with both indices range-checked
+      int2 e = cand[k];
+      e.x = checked(e.x, n_samples, cnt, 9);
+      e.y = checked(e.y, n_group, cnt, 10);
+      return e;
+    };
+    int2 c = i < n ? entry(i) : make_int2(0, 0);
+    int ti = i < n ? checked(group[c.y], n_tris, cnt, 11) : 0;
     int bp = i < n ? best_pos[c.x] : 0;
     while (i < n) {
       const int inext = i + stride;
-      const int2 cn = inext < n ? cand[inext] : c;
-      const int tin = group[cn.y];
+      const int2 cn = inext < n ? entry(inext) : c;
+      const int tin = checked(group[cn.y], n_tris, cnt, 11);
       const int bpn = best_pos[cn.x];
       const int s = c.x;
       if (bp == c.y) {  // else another triangle of this ray is listed earlier, or the pair was no hit
@@ -1577,7 +1615,8 @@ k_shade_candidates(ShadeConst fc, SceneDev sc, TopTreeArgs ta, const f2* __restr
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_resolve(FrameConst fc, const int2* __restrict__ blocks, int npix, const int* __restrict__ hit_id,
-          const double* __restrict__ rgb, const rtmi_object* __restrict__ objects, unsigned char* rgba, int* hit_out) {
+          const double* __restrict__ rgb, const rtmi_object* __restrict__ objects, int n_objects, DevCounters* cnt,
+          unsigned char* rgba, int* hit_out) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= npix) return;
   int b = p >> 6, pix = p & (BLK_PIX - 1);
@@ -1588,7 +1627,7 @@ k_resolve(FrameConst fc, const int2* __restrict__ blocks, int npix, const int* _
     int s = ((b * fc.spp + q) << 6) + pix;
     int id = hit_id[s];
     // a bounding object's marker that no child hit has replaced: the ray hit nothing (RTF:86-93)
-    if (id <= -2 && objects[-2 - id].kind == RTMI_BOUNDING_SPHERE) id = -1;
+    if (id <= -2 && objects[checked(-2 - id, n_objects, cnt, 20)].kind == RTMI_BOUNDING_SPHERE) id = -1;
     double r = 0.0, g = 0.0, bl = 0.0;  // RGB.black for a miss
     if (id != -1) {
       r = rgb[(size_t)s * 3 + 0];
@@ -1628,7 +1667,8 @@ struct TriGroup {
   float* d_tedge = nullptr;
   NodeCone* d_nodes = nullptr;
   unsigned int* d_ticket = nullptr;
-  TreeHost tree_host;  // host copy of the slot order, kept until the scene is built
+  size_t n_records = 0;  // records of the tree, all levels
+  TreeHost tree_host;    // host copy of the slot order, kept until the scene is built
   // which operands the device holds: 0 none, 1 cone tree, 2 list scan -- and for which camera position
   int packed_for = 0;
   double packed_cam[3] = {0, 0, 0};
@@ -1746,6 +1786,7 @@ static int32_t alloc_group(TriGroup& g, const std::vector<int>& idx, const rtmi_
   TreeHost& th = g.tree_host;
   tree_build_host(tris, idx, &th);
   g.tree = th.dev;
+  g.n_records = th.n_records;
   const size_t ns = th.slot_tri.size();
   HIP_TRY(hipMalloc(&g.d_slot_tri, sizeof(int) * ns));
   HIP_TRY(hipMemcpy(g.d_slot_tri, th.slot_tri.data(), sizeof(int) * ns, hipMemcpyHostToDevice));
@@ -1986,6 +2027,7 @@ static int32_t scene_create_impl(const rtmi_scene_desc* desc, int32_t device, rt
     sc->top_args.ltop = td.ltop;
     sc->top_args.n_root = td.n_root;
     sc->top_args.n_slots = td.n_slots;
+    sc->top_args.n_records = (int)sc->groups[0].n_records;
     for (int l = 0; l < TREE_MAX_LEVELS; ++l) sc->top_args.off[l] = td.rec_off[l];
   }
   for (auto& g : sc->groups) g.tree_host = TreeHost();  // host copies are not needed any more
@@ -2002,6 +2044,7 @@ static int32_t scene_create_impl(const rtmi_scene_desc* desc, int32_t device, rt
   sc->dev.tris = sc->d_tris;
   sc->dev.planes = sc->d_planes;
   sc->dev.n_objects = (int)desc->n_objects;
+  sc->dev.n_tris = (int)desc->n_triangles;
   sc->dev.n_lights = desc->n_lights;
   sc->dev.n_sphere_like = n_sphere_like;
   sc->dev.n_top_tris = (long long)top.size();
@@ -2215,6 +2258,7 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
   const size_t max_batch_blocks = std::min(blocks_per_batch, std::max<size_t>(blocks.size(), 1));
   int32_t rc = ensure_buffers(sc, max_batch_blocks * samples_per_block, std::max<size_t>(blocks.size(), 1));
   if (rc) return rc;
+  sc->dev.n_samples = (int)std::min<size_t>(sc->cap_samples, 0x7fffffff);
 
   hipStream_t st = sc->stream;
   HIP_TRY(hipEventRecord(sc->ev_a, st));
@@ -2314,6 +2358,9 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
     a.best_pos = sc->d_best_pos;
     a.cand = sc->d_cand;
     a.n_group = g.n;
+    a.n_samples = (int)std::min<size_t>(sc->cap_samples, 0x7fffffff);
+    a.n_tris = (int)sc->n_tris;
+    a.n_records = (int)g.n_records;
     a.cand_cap = (int)std::min<size_t>(sc->cap_cand, 0x7fffffff);
     a.tree = g.tree;
   }
@@ -2402,7 +2449,7 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
     }
     int npix = (int)(nb * BLK_PIX);
     hipLaunchKernelGGL(k_resolve, dim3((npix + 255) / 256), dim3(256), 0, st, fc, d_blk, npix, sc->d_hit_id, sc->d_rgb,
-                       (const rtmi_object*)sc->d_objects, (unsigned char*)rgba_dev, (int*)hit_dev);
+                       (const rtmi_object*)sc->d_objects, sc->dev.n_objects, sc->d_cnt, (unsigned char*)rgba_dev, (int*)hit_dev);
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipEventRecord(sc->ev_b, st));
@@ -2450,6 +2497,12 @@ static int32_t render_end_impl(rtmi_scene* sc, rtmi_counters* counters) {
     sc->pend_params.search = RTMI_SEARCH_CONE_TREE;
   }
   const DevCounters& hc = *sc->h_cnt;
+  if (hc.bug) {
+    // an index read from device memory was out of range (checked() in the kernels replaced it and
+    // went on): the frame cannot be trusted
+    g_last_error = "internal index check " + std::to_string(hc.bug) + " failed on the device; the frame is not valid";
+    return RTMI_ERR_HIP;
+  }
   float ms_total = 0.f, ms_search = 0.f, ms_shade = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms_total, sc->ev_a, sc->ev_b));
   for (size_t i = 0; i < sc->ev_used; ++i) {
