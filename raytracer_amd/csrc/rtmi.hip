@@ -793,7 +793,7 @@ k_resolve_top(SceneDev sc, const int* __restrict__ q_top, const int* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------
-// k_search_primary: the hot kernel
+// k_search_primary: the list scan (RTMI_SEARCH_LIST_SCAN)
 // ---------------------------------------------------------------------------------------
 // Each lane owns R rays (queue entries base + r*64 + lane) that share the camera origin.
 // Every (ray, triangle) pair goes through a cascade of three tests, cheapest first:
@@ -817,9 +817,11 @@ k_resolve_top(SceneDev sc, const int* __restrict__ q_top, const int* __restrict_
 // mode 0: queue entries are sample ids awaiting the children of bounding object
 //         `obj_filter`; the result is written to hit_id[s] and hits are appended to q_shade.
 // mode 1: top-level runs; the result (triangle index or -1) goes to tri_hit[q].
-// Everything the search kernel needs besides the cone stream.  It lives in device memory and is
-// read where it is used (prologue, rare path, epilogue), so that the steady-state loop keeps its
-// scalar registers for the two triangle batches in flight.
+// (Both modes apply to the cone tree's kernels as well.)
+
+// Everything a search kernel needs besides its operand stream, one block per triangle group.  It
+// lives in device memory and is read where it is used (prologue, rare path, epilogue), so that the
+// list scan's steady-state loop keeps its scalar registers for the two triangle batches in flight.
 struct SearchArgs {
   const int* queue;
   const int* nq_ptr;
@@ -840,7 +842,7 @@ struct SearchArgs {
   int n_group;       // triangles in the group (entries of `group`)
   int n_samples, n_tris, n_records;  // entries of the per-sample arrays, of tris/planes, of the tree's records
   int* best_pos;     // per sample: lowest list position hit so far (tree search)
-  int2* cand;        // (sample, triangle slot) candidates of the tree search
+  int2* cand;        // (sample, list position) candidates of the tree search, NSLOT lists of cand_cap / NSLOT
   int cand_cap;
   TreeDev tree;
 };
