@@ -245,6 +245,12 @@ int32_t rtmi_obj_material_count(const rtmi_obj_mesh* mesh);
 const rtmi_material* rtmi_obj_materials(const rtmi_obj_mesh* mesh);   /* owned by the mesh */
 const char* rtmi_obj_material_name(const rtmi_obj_mesh* mesh, int32_t index);
 
+/* loadObjFile (ViewController.swift:84-105) in one call: the OBJ's triangles (materials from the MTL,
+ * mtl_path may be NULL) wrapped in Sphere(boundingObjects:) -- a bounding sphere without a material, the
+ * scene's only object -- plus the caller's lights, uploaded to `device`. */
+int32_t rtmi_scene_from_obj(const char* obj_path, const char* mtl_path, const rtmi_light* lights,
+                            int32_t n_lights, int32_t device, rtmi_scene** out);
+
 /* ---- image output (host only) ----------------------------------------------------------- */
 
 /* Write the RGBA8 frame (4*width bytes per row, as rtmi_render fills it) as a binary PPM (RGB) or

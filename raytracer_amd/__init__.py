@@ -74,6 +74,8 @@ def lib():
         for name in ("rtmi_write_ppm", "rtmi_write_png"):
             getattr(L, name).restype = C.c_int32
             getattr(L, name).argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]
+        L.rtmi_scene_from_obj.restype = C.c_int32
+        L.rtmi_scene_from_obj.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
         L.rtmi_tree_slot_order.restype = C.c_int32
         L.rtmi_tree_slot_order.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
         if L.rtmi_abi_version() != _abi.RTMI_ABI_VERSION:
@@ -152,6 +154,19 @@ class Scene:
         self.device = device
         desc = data.desc()
         _check(lib().rtmi_scene_create(C.byref(desc), device, C.byref(self._h)), "rtmi_scene_create")
+
+    @classmethod
+    def from_obj(cls, obj_path, mtl_path=None, lights=None, device: int = 0):
+        """loadObjFile in one call (rtmi_scene_from_obj): the mesh wrapped in Sphere(boundingObjects:)."""
+        self = cls.__new__(cls)
+        self._h = C.c_void_p()
+        self.data = None
+        self.device = device
+        lights = np.ascontiguousarray(lights if lights is not None else np.zeros(0, scenes.LIGHT_DTYPE))
+        rc = lib().rtmi_scene_from_obj(os.fsencode(obj_path), os.fsencode(mtl_path) if mtl_path else None,
+                                       lights.ctypes.data if len(lights) else None, len(lights), device, C.byref(self._h))
+        _check(rc, "rtmi_scene_from_obj")
+        return self
 
     def close(self):
         if self._h:

@@ -83,5 +83,5 @@ EXPORTS = [
     "rtmi_render_device", "rtmi_render_begin", "rtmi_render_end", "rtmi_samples_per_pixel",
     "rtmi_obj_load", "rtmi_obj_free", "rtmi_obj_vertex_count", "rtmi_obj_triangle_count", "rtmi_obj_triangles",
     "rtmi_obj_material_count", "rtmi_obj_materials", "rtmi_obj_material_name",
-    "rtmi_write_ppm", "rtmi_write_png", "rtmi_tree_slot_order",
+    "rtmi_write_ppm", "rtmi_write_png", "rtmi_tree_slot_order", "rtmi_scene_from_obj",
 ]

@@ -271,3 +271,36 @@ extern "C" const char* rtmi_obj_material_name(const rtmi_obj_mesh* mesh, int32_t
 }
 
 extern "C" int64_t rtmi_obj_vertex_count(const rtmi_obj_mesh* mesh) { return mesh ? mesh->n_vertices : 0; }
+
+// loadObjFile (ViewController.swift:84-105) in one call: read the OBJ (and MTL), build the triangle
+// list and wrap it in Sphere(boundingObjects:) -- `t = [Sphere(boundingObjects: triangles)]`, a
+// bounding sphere without a material -- as the scene's only object, with the caller's lights.
+extern "C" int32_t rtmi_scene_from_obj(const char* obj_path, const char* mtl_path, const rtmi_light* lights,
+                                       int32_t n_lights, int32_t device, rtmi_scene** out) {
+  if (!out) return RTMI_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  if (n_lights < 0 || (n_lights > 0 && !lights)) return RTMI_ERR_INVALID_ARGUMENT;
+  rtmi_obj_mesh* mesh = nullptr;
+  int32_t rc = rtmi_obj_load(obj_path, mtl_path, &mesh);
+  if (rc != RTMI_OK) return rc;
+  rtmi_object bound{};
+  bound.kind = RTMI_BOUNDING_SPHERE;
+  bound.material = -1;
+  bound.first = 0;
+  bound.count = (int64_t)mesh->triangles.size();
+  rc = rtmi_bounding_sphere(mesh->triangles.data(), bound.count, bound.center, &bound.radius);
+  if (rc == RTMI_OK) {
+    rtmi_scene_desc desc{};
+    desc.lights = lights;
+    desc.n_lights = n_lights;
+    desc.materials = mesh->materials.empty() ? nullptr : mesh->materials.data();
+    desc.n_materials = (int32_t)mesh->materials.size();
+    desc.objects = &bound;
+    desc.n_objects = 1;
+    desc.triangles = mesh->triangles.empty() ? nullptr : mesh->triangles.data();
+    desc.n_triangles = bound.count;
+    rc = rtmi_scene_create(&desc, device, out);
+  }
+  delete mesh;
+  return rc;
+}

@@ -95,3 +95,46 @@ def test_loaded_cube_renders_like_the_oracle(oracle_mod):
     sc.close()
     assert (g_hit == o_hit).all() and (g_rgba == o_rgba).all()
     assert len(set(np.unique(o_hit)) - {-1}) >= 3, "several cube faces must be visible"
+
+
+def test_scene_from_obj_rejects_bad_input_without_a_device(tmp_path):
+    # argument and parse errors are reported before any device is touched
+    with pytest.raises(rt.RtmiError) as ei:
+        rt.Scene.from_obj(str(tmp_path / "missing.obj"))
+    assert ei.value.status == _abi.RTMI_ERR_INVALID_ARGUMENT
+    bad = tmp_path / "bad.obj"
+    bad.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1/1 2/2 3/3\n")
+    with pytest.raises(rt.RtmiError):
+        rt.Scene.from_obj(str(bad))
+
+
+@pytest.mark.gpu
+def test_scene_from_obj_equals_the_hand_built_scene(oracle_mod):
+    """rtmi_scene_from_obj = loadObjFile: load + Sphere(boundingObjects:) + upload; same frame as the
+    scene assembled by hand, and as the oracle's."""
+    from raytracer_amd import scenes
+    lights = np.concatenate([scenes.light(**scenes.L1), scenes.light(**scenes.L3)])
+    tris, mats, names, _ = rt.load_obj(os.path.join(DATA, "cube.obj"), os.path.join(DATA, "cube.mtl"))
+    c, r = rt.bounding_sphere(tris)
+    data = scenes.SceneData(lights=lights, materials=mats,
+                            objects=scenes.sphere_object(c, r, -1, bounding=True, first=0, count=len(tris)), triangles=tris)
+    cam = scenes.make_camera((1.2, 0.9, 3.0), (-0.35, -0.25, -1.0), 8.0)
+    params = scenes.make_params(96, 96, 0.5)
+    o_rgba, o_hit, _ = oracle_mod.render(data, cam, params)
+    sc = rt.Scene.from_obj(os.path.join(DATA, "cube.obj"), os.path.join(DATA, "cube.mtl"), lights)
+    g_rgba, g_hit, _ = sc.render(cam, params)
+    sc.close()
+    assert (g_hit == o_hit).all() and (g_rgba == o_rgba).all()
+
+
+@pytest.mark.gpu
+def test_command_line_harness_writes_the_rendered_frame(tmp_path):
+    from raytracer_amd import render
+    from test_image_writer import decode_png
+    out = tmp_path / "cube.png"
+    cnt = render.main([os.path.join(DATA, "cube.obj"), str(out), "--mtl", os.path.join(DATA, "cube.mtl"), "--size", "120", "90",
+                       "--camera", "1.2", "0.9", "3.0", "--direction", "-0.35", "-0.25", "-1.0", "--focal-length", "8",
+                       "--subdivision", "0.5"])
+    img = decode_png(out)
+    assert img.shape == (90, 120, 4) and cnt["primary_hits"] > 0
+    assert (img[:89, :119, 3] == 255).all() and img[:, :, :3].max() > 0
