@@ -168,6 +168,48 @@ def test_random_mixed_object_lists(oracle_mod, rt, seed):
     assert_parity(oracle_mod, rt, data, cam, scenes.make_params(96, 80, 0.5, ambient=(0.3, 0.2, 0.25)))
 
 
+def test_many_bounding_groups_in_one_scene(oracle_mod, rt):
+    """Seven bounded meshes of different sizes (one of them empty, two overlapping on screen) plus spheres in
+    between: seven search launches per frame, alternating between the two sets of candidate-list counters."""
+    rng = np.random.default_rng(21)
+    sizes = [300, 9, 0, 64, 1, 513, 40]
+    soups, objs, first = [], [], 0
+    for k, n in enumerate(sizes):
+        centre = np.array([(k % 4 - 1.5) * 1.3, (k // 4 - 0.5) * 1.6, -0.5 * (k % 2)])
+        t = random_soup(rng, n, 0.35, 0.4)
+        t["v"] += centre
+        soups.append(t)
+        c, r = rt.bounding_sphere(t) if n else ((float(centre[0]), float(centre[1]), float(centre[2])), 0.5)
+        objs.append(scenes.sphere_object(c, r, 1 if k == 3 else -1, bounding=True, first=first, count=n))
+        if k in (1, 4):
+            objs.append(scenes.sphere_object(centre + (0.2, 0.1, 0.6), 0.3, 0))
+        first += n
+    data = scenes.SceneData(lights=three_lights(), materials=TWO_MATS, objects=np.concatenate(objs), triangles=np.concatenate(soups))
+    cam = scenes.make_camera((0.2, 0.1, 7.0), (-0.02, 0.0, -1.0), 9.0)
+    o, g = assert_parity(oracle_mod, rt, data, cam, scenes.make_params(200, 150, 0.5))
+    assert o["primary_hits"] > 0
+    # the same scene again after another one has used the device in between (per-scene state only)
+    other = rt.Scene(scenes.two_sphere_scene())
+    sc = rt.Scene(data)
+    a, ah, _ = sc.render(cam, scenes.make_params(200, 150, 0.5))
+    other.render(scenes.make_camera(**scenes.VC_CAMERA), scenes.make_params(64, 64))
+    b, bh, _ = sc.render(cam, scenes.make_params(200, 150, 0.5))
+    other.close()
+    sc.close()
+    assert (a == b).all() and (ah == bh).all()
+
+
+def test_two_hundred_spheres(oracle_mod, rt):
+    """A long object list of plain spheres (the pre-test of ray generation holds one cone per object)."""
+    rng = np.random.default_rng(22)
+    objs = [scenes.sphere_object(rng.uniform(-4, 4, 3) * (1, 1, 0.3), float(rng.uniform(0.05, 0.4)), int(rng.integers(-1, 2)))
+            for _ in range(200)]
+    data = scenes.SceneData(lights=three_lights(), materials=TWO_MATS, objects=np.concatenate(objs))
+    cam = scenes.make_camera((0.0, 0.0, 12.0), (0.0, 0.0, -1.0), 10.0)
+    o, g = assert_parity(oracle_mod, rt, data, cam, scenes.make_params(160, 120, 0.5))
+    assert o["primary_hits"] > 1000
+
+
 def test_rays_through_shared_edges_and_vertices(oracle_mod, rt):
     """A planar grid whose vertices sit exactly on pixel-corner rays: every such ray passes through
     a shared vertex/edge (inclusive tests, Renderables.swift:161-163), and the lowest list position
