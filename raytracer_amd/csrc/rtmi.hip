@@ -1999,6 +1999,8 @@ static int32_t scene_create_impl(const rtmi_scene_desc* desc, int32_t device, rt
     double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     double slo[3] = {INFINITY, INFINITY, INFINITY}, shi[3] = {-INFINITY, -INFINITY, -INFINITY};
     auto grow = [](double* l, double* h, const double* p, double r) {
+      // non-finite coordinates (such triangles are never hit) must not reach the FP32 frame of reference
+      if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2]) || !std::isfinite(r)) return;
       for (int a = 0; a < 3; ++a) { l[a] = std::min(l[a], p[a] - r); h[a] = std::max(h[a], p[a] + r); }
     };
     for (int ti : top) for (int k = 0; k < 3; ++k) grow(lo, hi, desc->triangles[ti].v[k], 0.0);
@@ -2015,7 +2017,10 @@ static int32_t scene_create_impl(const rtmi_scene_desc* desc, int32_t device, rt
       r_o1 += std::max(fabs(slo[a] - c0[a]), fabs(shi[a] - c0[a]));
     }
     r_o1 *= 1.01;
-    if (!std::isfinite(r_o1)) r_o1 = 0.0;  // the filter then degrades to "always nominate" via its own checks
+    if (!std::isfinite(r_o1)) {  // no finite point at all: the filters then degrade to "always nominate" via their own checks
+      r_o1 = 0.0;
+      c0[0] = c0[1] = c0[2] = 0.0;
+    }
     const size_t nt = top.size();
     HIP_TRY(hipMalloc(&sc->d_gst2, sizeof(float) * GST2_FLOATS * nt));
     hipLaunchKernelGGL(k_pack_general, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, sc->stream, sc->d_tris,

@@ -256,6 +256,26 @@ def test_degenerate_and_backfacing_triangles(oracle_mod, rt):
     assert_parity(oracle_mod, rt, data, cam, scenes.make_params(128, 128, 0.5))
 
 
+@pytest.mark.parametrize("form", ["B", "T"])
+def test_non_finite_vertices_are_never_hit(oracle_mod, rt, form):
+    """Triangles with NaN or infinite coordinates (never hit in the reference: every comparison with NaN
+    is false) among ordinary ones, bounded and at top level."""
+    rng = np.random.default_rng(9)
+    tris = random_soup(rng, 120, 0.5, 1.0)
+    tris["v"][10, 1, 2] = np.nan
+    tris["v"][11] = np.nan
+    tris["v"][40, 0, 0] = np.inf
+    tris["v"][41, 2] = -np.inf
+    if form == "B":
+        objs = scenes.sphere_object((0.0, 0.0, 0.0), 3.0, -1, bounding=True, first=0, count=len(tris))
+    else:
+        objs = scenes.triangles_object(0, len(tris))
+    data = scenes.SceneData(lights=three_lights(), materials=TWO_MATS, objects=objs, triangles=tris)
+    cam = scenes.make_camera((0.1, 0.0, 6.0), (0, 0, -1), 8.0)
+    o, g = assert_parity(oracle_mod, rt, data, cam, scenes.make_params(100, 90, 0.5))
+    assert o["primary_hits"] > 0
+
+
 def test_camera_inside_mesh_and_far_scale(oracle_mod, rt):
     # camera inside the bounded mesh: only back faces ahead -> nothing but what the oracle says
     data = scenes.mesh_scene(2, "B", 1, bounding_sphere=rt.bounding_sphere)
