@@ -2144,7 +2144,18 @@ static int search_rays_per_lane() {
   }();
   return r;
 }
-constexpr size_t MAX_BATCH_SAMPLES = 1u << 28;  // 256 Mi samples per batch (68 B of work buffers per sample)
+constexpr size_t MAX_BATCH_SAMPLES = 1u << 28;  // 256 Mi samples per batch (about 100 B of work buffers per sample)
+
+// Frames with more samples than this are rendered in several batches of whole pixel blocks.
+// RTMI_MAX_BATCH_SAMPLES lowers it (tests use that to take the multi-batch path with small frames).
+static size_t max_batch_samples() {
+  static size_t v = [] {
+    const char* e = getenv("RTMI_MAX_BATCH_SAMPLES");
+    long long x = e ? atoll(e) : 0;
+    return x > 0 ? std::min<size_t>((size_t)x, MAX_BATCH_SAMPLES) : MAX_BATCH_SAMPLES;
+  }();
+  return v;
+}
 
 // Enqueue a whole frame on the scene's stream; nothing here waits for the device.  The caller
 // holds sc->mu.
@@ -2261,7 +2272,7 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
     fc.tile_size = 0;
   }
   const size_t samples_per_block = (size_t)BLK_PIX * spp;
-  const size_t blocks_per_batch = std::max<size_t>(1, MAX_BATCH_SAMPLES / samples_per_block);
+  const size_t blocks_per_batch = std::max<size_t>(1, max_batch_samples() / samples_per_block);
   const size_t max_batch_blocks = std::min(blocks_per_batch, std::max<size_t>(blocks.size(), 1));
   int32_t rc = ensure_buffers(sc, max_batch_blocks * samples_per_block, std::max<size_t>(blocks.size(), 1));
   if (rc) return rc;

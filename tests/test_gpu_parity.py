@@ -368,6 +368,18 @@ def test_tiles_that_are_not_multiples_of_the_pixel_blocks(rt):
     sc.close()
 
 
+def test_frames_rendered_in_several_batches():
+    """A frame with more samples than the batch limit is rendered batch by batch (queues, candidate lists and
+    per-sample arrays are reused); the limit is lowered through the environment in a process of its own."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, RTMI_MAX_BATCH_SAMPLES="4096")
+    r = subprocess.run([sys.executable, os.path.join(here, "multibatch_check.py")], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "multibatch ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_render_errors(rt):
     sc = rt.Scene(scenes.two_sphere_scene())
     cam = scenes.make_camera(**scenes.VC_CAMERA)
