@@ -380,6 +380,48 @@ def test_frames_rendered_in_several_batches():
     assert r.returncode == 0 and "multibatch ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_begin_end_protocol_and_two_threads(oracle_mod, rt):
+    import threading
+    import torch
+    data_a = scenes.mesh_scene(3, "B", 2, bounding_sphere=rt.bounding_sphere)
+    data_b = scenes.two_sphere_scene()
+    cam_a, cam_b = scenes.make_camera(**scenes.MESH_CAMERA), scenes.make_camera(**scenes.VC_CAMERA)
+    pa, pb = scenes.make_params(160, 120, 0.5), scenes.make_params(200, 200)
+    # one frame in flight per scene: a second begin, or an end without a begin, is an error
+    sc = rt.Scene(data_a)
+    frame = torch.zeros((120, 160, 4), dtype=torch.uint8, device="cuda:0")
+    with pytest.raises(rt.RtmiError):
+        sc.render_end()
+    sc.render_begin(cam_a, pa, frame.data_ptr())
+    with pytest.raises(rt.RtmiError):
+        sc.render_begin(cam_a, pa, frame.data_ptr())
+    sc.render_end()
+    expect_a, _, _ = oracle_mod.render(data_a, cam_a, pa, want_hit_ids=False, threads=8)
+    assert (frame.cpu().numpy() == expect_a).all()
+    sc.close()
+    # two host threads, each with a scene of its own, rendering at the same time
+    expect_b, _, _ = oracle_mod.render(data_b, cam_b, pb, want_hit_ids=False, threads=8)
+    errors = []
+
+    def work(data, cam, params, expect):
+        try:
+            s = rt.Scene(data)
+            for _ in range(5):
+                got, _, _ = s.render(cam, params, want_hit_ids=False)
+                if not (got == expect).all():
+                    errors.append("frame differs")
+            s.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=a) for a in ((data_a, cam_a, pa, expect_a), (data_b, cam_b, pb, expect_b))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
 def test_render_errors(rt):
     sc = rt.Scene(scenes.two_sphere_scene())
     cam = scenes.make_camera(**scenes.VC_CAMERA)
