@@ -394,6 +394,14 @@ def cpu_baseline(data, params, threads):
     _, _, cnt = oracle.render(data, cam, p, want_hit_ids=False, threads=threads)
     dt = time.perf_counter() - t0
     rays = cnt["samples"] + cnt["rays_reflection"] + cnt["rays_shadow"]
+    # the reference itself is single-threaded (ViewController.swift:154): one thread on a sixteenth of the window
+    sw, sh = max(ww // 4, 1), max(wh // 4, 1)
+    sx, sy = (W - 1 - sw) // 2, (H - 1 - sh) // 2
+    p1 = scenes.make_params(W, H, params.pixel_subdivision, tuple(params.ambient), window=(sx, sy, sx + sw, sy + sh))
+    t1 = time.perf_counter()
+    _, _, c1 = oracle.render(data, cam, p1, want_hit_ids=False, threads=1)
+    d1 = time.perf_counter() - t1
+    rays1 = c1["samples"] + c1["rays_reflection"] + c1["rays_shadow"]
     return {
         "value": round(rays / dt / 1e6, 4),
         "unit": "Mrays/s",
@@ -404,6 +412,9 @@ def cpu_baseline(data, params, threads):
                   "so its rays are costlier than the frame average",
         "tests_per_s": cnt["tri_tests"] / dt,
         "seconds": round(dt, 2),
+        "single_thread": {"value": round(rays1 / d1 / 1e6, 4), "unit": "Mrays/s", "cores": 1,
+                          "sample": f"centre window {sw}x{sh} px ({c1['samples']} primary rays, {d1:.1f} s)",
+                          "tests_per_s": c1["tri_tests"] / d1},
     }
 
 

@@ -1920,7 +1920,13 @@ static int32_t scene_create_impl(const rtmi_scene_desc* desc, int32_t device, rt
     return RTMI_ERR_NO_DEVICE;
   }
   sc->device = device;
-  sc->exact_grid = ((std::max(1, prop.multiProcessorCount) * 8 + NSLOT - 1) / NSLOT) * NSLOT;  // a multiple of NSLOT
+  {
+    // workgroups of the grid-stride kernels: RTMI_GRID_PER_CU per compute unit (default 8), a multiple of NSLOT
+    const char* e = getenv("RTMI_GRID_PER_CU");
+    int per_cu = e ? atoi(e) : 8;
+    if (per_cu < 1 || per_cu > 64) per_cu = 8;
+    sc->exact_grid = ((std::max(1, prop.multiProcessorCount) * per_cu + NSLOT - 1) / NSLOT) * NSLOT;
+  }
   HIP_TRY(hipSetDevice(device));
   HIP_TRY(hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreate(&sc->ev_a));
