@@ -1,0 +1,58 @@
+"""Runs scenes through the CPU-emulated build of the HIP kernels (tests/emu): test infrastructure."""
+import ctypes as C
+import os
+import re
+import struct
+import subprocess
+
+import numpy as np
+
+from raytracer_amd import _abi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMU_DIR = os.path.join(HERE, "emu")
+EMU_BIN = os.path.join(EMU_DIR, "build", "emu_render")
+
+
+def build(sanitize=True):
+    args = ["make", "-s", "-C", EMU_DIR]
+    if not sanitize:
+        args.append("SAN=")
+    subprocess.check_call(args)
+
+
+def run_emulated(data, cameras, params, workdir, want_hit=True, frames_per_scene=0, env=None, timeout=900):
+    """Render `cameras` (a list) of scene `data`; returns (frames, stats, stdout) where frames is a list of
+    (rgba[H,W,4] u8, hit[H,W,spp] i32 or None, Counters) and stats maps kernel name -> dict of emulator totals."""
+    workdir = str(workdir)
+    os.makedirs(workdir, exist_ok=True)
+    for k, a in data.to_arrays().items():
+        np.ascontiguousarray(a).tofile(os.path.join(workdir, k + ".bin"))
+    with open(os.path.join(workdir, "job.bin"), "wb") as f:
+        f.write(struct.pack("<4i", len(cameras), int(want_hit), int(frames_per_scene), 0))
+        f.write(bytes(params))
+        for c in cameras:
+            f.write(bytes(c))
+    e = dict(os.environ)
+    e.setdefault("ASAN_OPTIONS", "detect_leaks=0:abort_on_error=0:detect_stack_use_after_return=0")
+    e.setdefault("UBSAN_OPTIONS", "print_stacktrace=1")
+    e.update(env or {})
+    r = subprocess.run([EMU_BIN, workdir], capture_output=True, text=True, timeout=timeout, env=e)
+    if r.returncode != 0:
+        raise AssertionError(f"emu_render exit {r.returncode}\n{r.stdout[-3000:]}\n{r.stderr[-6000:]}")
+    W, H = params.width, params.height
+    frames = []
+    for k in range(len(cameras)):
+        rgba = np.fromfile(os.path.join(workdir, f"rgba_{k}.bin"), np.uint8).reshape(H, W, 4)
+        hit = None
+        if want_hit:
+            hit = np.fromfile(os.path.join(workdir, f"hit_{k}.bin"), np.int32).reshape(H, W, -1)
+        with open(os.path.join(workdir, f"counters_{k}.bin"), "rb") as f:
+            cnt = _abi.Counters.from_buffer_copy(f.read(C.sizeof(_abi.Counters)))
+        frames.append((rgba, hit, cnt))
+    stats = {}
+    for line in r.stdout.splitlines():
+        if line.startswith("emu-stats "):
+            head, name = line.split(" kernel=", 1)  # the name is the launch expression as written, spaces included
+            stats[name] = {k: int(v) for k, v in re.findall(r"(\w+)=(\d+)", head)}
+    return frames, stats, r.stdout

@@ -1,0 +1,157 @@
+"""The HIP kernels, compiled unchanged as host C++ against a CPU stand-in for the HIP runtime (tests/emu) and
+run under AddressSanitizer + UBSan: every work-item is a fiber, every "device" buffer a malloc block filled
+with garbage, wave-level operations and barriers are checked for agreement.  Results are held to the same
+bar as on the GPU: hit ids and RGBA8 identical to the oracle's.  This is a CPU-side check of the DEVICE code
+(indexing, barriers, uninitialised reads); it says nothing about speed and does not replace the GPU tests."""
+import copy
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+import emu_util
+from golden_util import golden_names, load_golden
+from raytracer_amd import _abi, scenes, sharding
+
+SEARCHES = {"tree": _abi.RTMI_SEARCH_CONE_TREE, "scan": _abi.RTMI_SEARCH_LIST_SCAN}
+PARITY_COUNTERS = ("samples", "rays_reflection", "rays_shadow", "sphere_tests", "primary_hits")
+# kernels whose wave-level votes are meant to be reached by part of a wave (the secondary-ray tree walk is
+# called from divergent shading code); everywhere else a vote that misses live lanes is a defect
+DIVERGENT_OK = ("k_shade<true>", "k_shade_candidates<true>")
+
+
+@pytest.fixture(scope="module")
+def emu():
+    emu_util.build()
+    subprocess.check_call(["make", "-s", "-C", emu_util.EMU_DIR, "build/emu_selftest"])
+    return emu_util
+
+
+def rendered_mask(p):
+    W, H = p.width, p.height
+    m = np.zeros((H, W), bool)
+    x0, y0, x1, y1 = (p.x0, p.y0, p.x1, p.y1) if (p.x0 or p.y0 or p.x1 or p.y1) else (0, 0, W - 1, H - 1)
+    m[y0:y1, x0:x1] = True
+    if p.tile_size > 0 and p.tile_world > 1:
+        m &= sharding.owned_pixel_mask(W, H, p.tile_rank, p.tile_world, p.tile_size)
+    return m
+
+
+def check_frames(frames, stats, expected, params):
+    mask = rendered_mask(params)
+    for k, (rgba, hit, cnt) in enumerate(frames):
+        o_rgba, o_hit, o_cnt = expected[k]
+        assert ((hit[..., 0] != -77) == mask).all(), f"frame {k}: the set of written samples is not the rendered set"
+        assert (rgba[~mask] == 0x5A).all(), f"frame {k}: bytes outside the rendered pixels were written"
+        assert (hit[mask] == o_hit[mask]).all(), f"frame {k}: {int((hit[mask] != o_hit[mask]).sum())} hit-id mismatches"
+        assert (rgba[mask] == o_rgba[mask]).all(), f"frame {k}: {int((rgba[mask] != o_rgba[mask]).sum())} RGBA8 byte mismatches"
+        if o_cnt is not None:
+            g = cnt.as_dict()
+            for key in PARITY_COUNTERS:
+                assert g[key] == o_cnt[key], (k, key)
+    for name, st in stats.items():
+        assert st["shfl_from_absent"] == 0, name
+        if not any(d in name for d in DIVERGENT_OK):
+            assert st["partial_wave_ops"] == 0, f"{name}: a wave-level vote or barrier was reached by part of a wave"
+
+
+def run_case(emu, oracle_mod, tmp_path, data, cams, params, searches=("tree", "scan"), env=None, frames_per_scene=0):
+    expected = [oracle_mod.render(data, c, params, threads=8) for c in cams]
+    ps = []
+    for s in searches:
+        ps.append(copy.copy(params))
+        ps[-1].search = SEARCHES[s]
+    with ThreadPoolExecutor(len(ps)) as pool:  # the emulated renders are child processes
+        jobs = [pool.submit(emu.run_emulated, data, cams, p, tmp_path / s, env=env, frames_per_scene=frames_per_scene)
+                for s, p in zip(searches, ps)]
+        for job, p in zip(jobs, ps):
+            frames, stats, _ = job.result()
+            check_frames(frames, stats, expected, p)
+    return expected
+
+
+def test_emulator_selftest(emu):
+    exe = emu.EMU_DIR + "/build/emu_selftest"
+    r = subprocess.run([exe, "ok"], capture_output=True, text=True)
+    assert r.returncode == 0 and "selftest ok" in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([exe, "ok"], capture_output=True, text=True, env={"EMU_SEED": "7"})
+    assert r.returncode == 0 and "selftest ok" in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([exe, "oob"], capture_output=True, text=True)
+    assert r.returncode != 0 and "heap-buffer-overflow" in r.stderr and "k_oob" in r.stderr
+    r = subprocess.run([exe, "barrier"], capture_output=True, text=True)
+    assert r.returncode != 0 and "different __syncthreads" in r.stderr
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_emulated_kernels_reproduce_golden(emu, tmp_path, name):
+    data, cam, params, rgba, hit, counters = load_golden(name)
+    ps = []
+    for search in SEARCHES.values():
+        ps.append(copy.copy(params))
+        ps[-1].search = search
+    with ThreadPoolExecutor(len(ps)) as pool:
+        # the same camera twice: the second frame takes the cached-preparation path
+        jobs = [pool.submit(emu.run_emulated, data, [cam, cam], p, tmp_path / str(p.search)) for p in ps]
+        for job, p in zip(jobs, ps):
+            frames, stats, _ = job.result()
+            check_frames(frames, stats, [(rgba, hit, counters)] * 2, p)
+
+
+def test_emulated_deeper_tree_moving_camera(emu, oracle_mod, tmp_path):
+    # 1280 triangles: three levels of the cone tree; three cameras on one scene object (re-packed per position)
+    data = scenes.mesh_scene(level=3, form="B", n_lights=3, bounding_sphere=oracle_mod.bounding_sphere)
+    cams = [scenes.make_camera(**scenes.orbit_camera(f, 64)) for f in (0, 5, 5)]
+    run_case(emu, oracle_mod, tmp_path, data, cams, scenes.make_params(40, 36, 0.5))
+
+
+def test_emulated_tiles_and_window(emu, oracle_mod, tmp_path):
+    data = scenes.mesh_scene(level=2, form="B", n_lights=2, bounding_sphere=oracle_mod.bounding_sphere)
+    cam = scenes.make_camera((0, 0, 4), (0, 0, -1), 10.0)
+    run_case(emu, oracle_mod, tmp_path / "tiles", data, [cam], scenes.make_params(70, 50, 0.5, tile_size=32, tile_rank=1, tile_world=3))
+    run_case(emu, oracle_mod, tmp_path / "window", data, [cam], scenes.make_params(70, 50, 0.25, window=(13, 7, 58, 41)), searches=("tree",))
+
+
+def test_emulated_mixed_groups_with_bad_vertices(emu, oracle_mod, tmp_path):
+    """Two bounded groups, a top-level run, spheres and a light in the object list; some vertices are not finite."""
+    rng = np.random.default_rng(11)
+
+    def soup(n, centre, scale):
+        t = np.zeros(n, scenes.TRI_DTYPE)
+        c = np.asarray(centre) + rng.uniform(-0.6, 0.6, size=(n, 1, 3))
+        t["v"] = c + rng.normal(size=(n, 3, 3)) * scale
+        t["material"] = rng.integers(0, 2, size=n)
+        return t
+
+    a, b, top = soup(150, (-0.8, 0, 0), 0.25), soup(90, (0.9, 0.2, -0.5), 0.3), soup(40, (0, -0.6, 0.5), 0.35)
+    a["v"][7, 1, 2] = np.nan
+    b["v"][3, 0, 0] = np.inf
+    top["v"][5, 2, 1] = -np.inf
+    tris = np.concatenate([a, b, top])
+    mats = np.concatenate([scenes.material(**scenes.VC_MATERIAL),
+                           scenes.material(Ns=3.5, d=1.0, illum=2, Kd=(0.8, 0.3, 0.2), Ka=(0.2, 0.5, 0.9), Ks=(0.4, 0.9, 0.1))])
+    lights = np.concatenate([scenes.light(**scenes.L1), scenes.light(**scenes.L3)])
+    ca, ra = oracle_mod.bounding_sphere(a[np.isfinite(a["v"]).all(axis=(1, 2))])
+    cb, rb = oracle_mod.bounding_sphere(b[np.isfinite(b["v"]).all(axis=(1, 2))])
+    objects = np.concatenate([
+        scenes.sphere_object(ca, ra, -1, bounding=True, first=0, count=len(a)),
+        scenes.sphere_object((0.2, 0.9, -1.0), 0.4, 1),
+        scenes.triangles_object(len(a) + len(b), len(top)),
+        scenes.light_object(1),
+        scenes.sphere_object(cb, rb, 0, bounding=True, first=len(a), count=len(b)),
+    ])
+    data = scenes.SceneData(lights=lights, materials=mats, objects=objects, triangles=tris)
+    cam = scenes.make_camera((0.1, 0.2, 4), (0, -0.05, -1), 8.0)
+    run_case(emu, oracle_mod, tmp_path, data, [cam, cam], scenes.make_params(44, 38, 0.5))
+
+
+@pytest.mark.parametrize("env", [{"EMU_SEED": "3"}, {"EMU_SEED": "12", "EMU_FILL": "255"}, {"EMU_FILL": "0", "EMU_CUS": "5"},
+                                 {"RTMI_MAX_BATCH_SAMPLES": "2048", "EMU_SEED": "9"}])
+def test_emulated_schedules_fill_patterns_batches(emu, oracle_mod, tmp_path, env):
+    """Other interleavings of the waves of a workgroup, other contents of fresh device memory, another grid
+    size, a frame cut into several batches: none of them may change a byte."""
+    data = scenes.mesh_scene(level=2, form="T", n_lights=3)
+    data_b = scenes.mesh_scene(level=2, form="B", n_lights=3, bounding_sphere=oracle_mod.bounding_sphere)
+    cam = scenes.make_camera((0, 0, 4), (0, 0, -1), 10.0)
+    run_case(emu, oracle_mod, tmp_path / "T", data, [cam], scenes.make_params(36, 30, 0.5), searches=("tree",), env=env)
+    run_case(emu, oracle_mod, tmp_path / "B", data_b, [cam, cam], scenes.make_params(36, 30, 0.5), env=env)
