@@ -2104,6 +2104,12 @@ static int32_t ensure_buffers(rtmi_scene* sc, size_t samples, size_t blocks) {
     // A closed mesh that fills the frame yields about one candidate per sample; twice that, plus a
     // floor that keeps each of the NSLOT lists roomy when few waves share few lists (small frames).
     sc->cap_cand = 2 * samples + (size_t)NSLOT * 16384;
+    // RTMI_CAND_CAPACITY (entries, for tests): a small value makes the lists overflow, which sends the frame
+    // through the list scan instead (render_end)
+    if (const char* e = getenv("RTMI_CAND_CAPACITY")) {
+      const long long v = atoll(e);
+      if (v > 0) sc->cap_cand = (size_t)std::max<long long>(v, NSLOT);
+    }
     HIP_TRY(hipMalloc(&sc->d_cand, sizeof(int2) * sc->cap_cand));
     sc->cap_samples = samples;
   }

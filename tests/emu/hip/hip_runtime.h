@@ -59,6 +59,9 @@
 #define __noinline__ __attribute__((noinline))
 #define __launch_bounds__(...)
 #define __shared__ static  // one workgroup runs at a time, so function-local statics are per-workgroup storage
+#define __constant__
+#define __align__(n) alignas(n)
+#define HIP_SYMBOL(x) (&(x))  // a file-scope __device__ variable is an ordinary global here
 
 struct dim3 {
   unsigned x, y, z;
@@ -96,7 +99,7 @@ static inline int __clzll(unsigned long long v) { return v ? __builtin_clzll(v) 
 
 // ---- runtime API ------------------------------------------------------------------------
 typedef int hipError_t;
-enum : int { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNoDevice = 100, hipErrorLaunchFailure = 719 };
+enum : int { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorInvalidConfiguration = 9, hipErrorNoDevice = 100, hipErrorLaunchFailure = 719 };
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 enum : unsigned { hipStreamDefault = 0, hipStreamNonBlocking = 1, hipHostMallocDefault = 0 };
 struct emu_stream_s { int id; };
@@ -186,6 +189,8 @@ struct Machine {
     return (unsigned)((rng_state * 2685821657736338717ull) >> 33);
   }
   std::map<std::string, KernelStats> stats;
+  int last_error = 0;  // what hipGetLastError() returns next
+  long bad_launches = 0;
 };
 
 inline Machine& M() {
@@ -407,7 +412,13 @@ inline void launch(const char* name, void (*kernel)(KArgs...), dim3 grid, dim3 b
   std::tuple<std::decay_t<KArgs>...> held(static_cast<std::decay_t<KArgs>>(args)...);
   const std::function<void()> body = [&] { std::apply(kernel, held); };
   const int n = (int)(block.x * block.y * block.z);
-  if (n <= 0 || n > MAX_LANES) die("bad workgroup size");
+  if (n <= 0 || n > MAX_LANES || grid.x == 0 || grid.y == 0 || grid.z == 0) {
+    // the runtime rejects an empty grid or workgroup: nothing runs and the launch reports an error
+    fprintf(stderr, "emu: launch of %s with grid (%u,%u,%u) block (%u,%u,%u) rejected\n", name, grid.x, grid.y, grid.z, block.x, block.y, block.z);
+    m.last_error = 9;
+    ++m.bad_launches;
+    return;
+  }
   if (!m.lanes) {
     m.lanes = new Lane[MAX_LANES];
     m.stacks = (char*)mmap(nullptr, (size_t)MAX_LANES * STACK_BYTES, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
@@ -438,6 +449,7 @@ inline void launch(const char* name, void (*kernel)(KArgs...), dim3 grid, dim3 b
 inline void report(FILE* f) {
   Machine& m = M();
   std::lock_guard<std::mutex> lock(m.mu);
+  fprintf(f, "emu-bad-launches %ld\n", m.bad_launches);
   for (const auto& kv : m.stats)
     fprintf(f, "emu-stats launches=%ld blocks=%ld wave_ops=%ld partial_wave_ops=%ld shfl_from_absent=%ld barriers=%ld kernel=%s\n",
             kv.second.launches, kv.second.blocks, kv.second.wave_ops, kv.second.partial_wave_ops, kv.second.shfl_from_absent,
@@ -539,6 +551,7 @@ static inline const char* hipGetErrorString(hipError_t e) {
     case hipErrorOutOfMemory: return "out of memory";
     case hipErrorInvalidValue: return "invalid argument";
     case hipErrorNoDevice: return "no device";
+    case hipErrorInvalidConfiguration: return "invalid configuration argument";
     default: return "emulated failure";
   }
 }
@@ -566,8 +579,17 @@ static inline hipError_t hipMemset(void* d, int v, size_t n) {
   return hipSuccess;
 }
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr) { return hipMemset(d, v, n); }
-static inline hipError_t hipGetLastError() { return hipSuccess; }
-static inline hipError_t hipPeekAtLastError() { return hipSuccess; }
+static inline hipError_t hipGetSymbolAddress(void** p, const void* symbol) { *p = const_cast<void*>(symbol); return hipSuccess; }
+static inline hipError_t hipMemcpyToSymbol(const void* symbol, const void* src, size_t n, size_t offset = 0, hipMemcpyKind = hipMemcpyHostToDevice) {
+  memmove((char*)const_cast<void*>(symbol) + offset, src, n);
+  return hipSuccess;
+}
+static inline hipError_t hipGetLastError() {
+  const int e = emu::M().last_error;
+  emu::M().last_error = 0;
+  return e;
+}
+static inline hipError_t hipPeekAtLastError() { return emu::M().last_error; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int* n) { *n = emu::env_int("EMU_DEVICES", 1); return hipSuccess; }
 static inline hipError_t hipSetDevice(int d) { return d >= 0 && d < emu::env_int("EMU_DEVICES", 1) ? hipSuccess : hipErrorInvalidValue; }

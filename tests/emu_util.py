@@ -51,6 +51,8 @@ def run_emulated(data, cameras, params, workdir, want_hit=True, frames_per_scene
             cnt = _abi.Counters.from_buffer_copy(f.read(C.sizeof(_abi.Counters)))
         frames.append((rgba, hit, cnt))
     stats = {}
+    if "emu-bad-launches 0" not in r.stdout:
+        raise AssertionError("a kernel launch was rejected (empty grid or workgroup)\n" + r.stdout[-2000:] + r.stderr[-2000:])
     for line in r.stdout.splitlines():
         if line.startswith("emu-stats "):
             head, name = line.split(" kernel=", 1)  # the name is the launch expression as written, spaces included

@@ -65,10 +65,12 @@ def run_case(emu, oracle_mod, tmp_path, data, cams, params, searches=("tree", "s
     with ThreadPoolExecutor(len(ps)) as pool:  # the emulated renders are child processes
         jobs = [pool.submit(emu.run_emulated, data, cams, p, tmp_path / s, env=env, frames_per_scene=frames_per_scene)
                 for s, p in zip(searches, ps)]
-        for job, p in zip(jobs, ps):
+        rendered = {}
+        for s, job, p in zip(searches, jobs, ps):
             frames, stats, _ = job.result()
             check_frames(frames, stats, expected, p)
-    return expected
+            rendered[s] = frames
+    return rendered
 
 
 def test_emulator_selftest(emu):
@@ -155,3 +157,25 @@ def test_emulated_schedules_fill_patterns_batches(emu, oracle_mod, tmp_path, env
     cam = scenes.make_camera((0, 0, 4), (0, 0, -1), 10.0)
     run_case(emu, oracle_mod, tmp_path / "T", data, [cam], scenes.make_params(36, 30, 0.5), searches=("tree",), env=env)
     run_case(emu, oracle_mod, tmp_path / "B", data_b, [cam, cam], scenes.make_params(36, 30, 0.5), env=env)
+
+
+@pytest.mark.parametrize("capacity", ["64", "1500"])
+def test_emulated_candidate_list_overflow(emu, oracle_mod, tmp_path, capacity):
+    """Candidate lists far too small for the frame (RTMI_CAND_CAPACITY): the search must notice, every kernel
+    after it must stay within bounds on the incomplete lists, and the frame comes out right through the list scan."""
+    cam = scenes.make_camera((0, 0, 4), (0, 0, -1), 10.0)
+    env = {"RTMI_CAND_CAPACITY": capacity}
+    data_b = scenes.mesh_scene(level=2, form="B", n_lights=3, bounding_sphere=oracle_mod.bounding_sphere)
+    out_b = run_case(emu, oracle_mod, tmp_path / "B", data_b, [cam, cam], scenes.make_params(36, 30, 0.5), searches=("tree",), env=env)
+    data_t = scenes.mesh_scene(level=2, form="T", n_lights=2)
+    out_t = run_case(emu, oracle_mod, tmp_path / "T", data_t, [cam, cam], scenes.make_params(30, 26, 0.5), searches=("tree",), env=env)
+    for out in (out_b, out_t):
+        for _, _, cnt in out["tree"]:  # the counters are those of the second rendering: no tree nodes, a scan instead
+            assert cnt.node_tests == 0 and cnt.tri_tests_primary_kernel > 0
+
+
+def test_emulated_random_scenes(emu, oracle_mod):
+    """A few cases of the scene fuzzer (tests/emu_fuzz.py); long runs of it are done by hand."""
+    import emu_fuzz
+    with ThreadPoolExecutor(4) as pool:
+        list(pool.map(lambda i: emu_fuzz.run_one(5, i, oracle_mod), range(8)))
