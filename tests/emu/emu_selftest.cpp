@@ -44,9 +44,16 @@ __global__ void k_lds(int* out) {
 
 __global__ void k_oob(int* p, int n) { p[threadIdx.x + n - 63] = 1; }  // the last lane writes p[n]
 
-__global__ void k_two_barriers() {
-  if (threadIdx.x < 64) __syncthreads();
-  else __syncthreads();
+__global__ void k_two_barriers(volatile int* out) {
+  // two barriers an optimiser cannot merge: different work before and after each
+  if (threadIdx.x < 64) {
+    out[threadIdx.x] = 1;
+    __syncthreads();
+  } else {
+    __syncthreads();
+    out[threadIdx.x] = 2;
+    __syncthreads();
+  }
 }
 
 __global__ void k_early_exit(int* out) {
@@ -67,7 +74,9 @@ int main(int argc, char** argv) {
     return 0;
   }
   if (!strcmp(what, "barrier")) {
-    hipLaunchKernelGGL(k_two_barriers, dim3(1), dim3(128), 0, nullptr);
+    int* p;
+    (void)hipMalloc(&p, 128 * sizeof(int));
+    hipLaunchKernelGGL(k_two_barriers, dim3(1), dim3(128), 0, nullptr, p);
     printf("no mismatch reported\n");
     return 0;
   }

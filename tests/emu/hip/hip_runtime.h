@@ -190,6 +190,7 @@ struct Machine {
   }
   std::map<std::string, KernelStats> stats;
   int last_error = 0;  // what hipGetLastError() returns next
+  long allocations = 0, fail_allocation = -1;  // fault injection: the allocation with this ordinal fails
   long bad_launches = 0;
 };
 
@@ -557,6 +558,7 @@ static inline const char* hipGetErrorString(hipError_t e) {
 }
 static inline hipError_t emu_alloc(void** p, size_t n) {
   if (!p) return hipErrorInvalidValue;
+  if (emu::M().allocations++ == emu::M().fail_allocation) return hipErrorOutOfMemory;
   void* q = nullptr;
   if (posix_memalign(&q, 256, n ? n : 1) != 0) return hipErrorOutOfMemory;
   memset(q, emu::env_int("EMU_FILL", 0xA5), n ? n : 1);  // fresh device memory is not zero

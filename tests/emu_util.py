@@ -34,7 +34,7 @@ def run_emulated(data, cameras, params, workdir, want_hit=True, frames_per_scene
         for c in cameras:
             f.write(bytes(c))
     e = dict(os.environ)
-    e.setdefault("ASAN_OPTIONS", "detect_leaks=0:abort_on_error=0:detect_stack_use_after_return=0")
+    e.setdefault("ASAN_OPTIONS", "detect_leaks=1:abort_on_error=0:detect_stack_use_after_return=0")
     e.setdefault("UBSAN_OPTIONS", "print_stacktrace=1")
     e.update(env or {})
     r = subprocess.run([EMU_BIN, workdir], capture_output=True, text=True, timeout=timeout, env=e)

@@ -85,6 +85,15 @@ def test_emulator_selftest(emu):
     assert r.returncode != 0 and "different __syncthreads" in r.stderr
 
 
+def test_emulated_api_lifecycle_and_allocation_failures(emu, oracle_mod):
+    """tests/emu/emu_api.cpp: one scene object across growing and shrinking frames, the begin/end protocol,
+    destruction with a frame in flight, every device allocation failing once; leak detection on."""
+    subprocess.check_call(["make", "-s", "-C", emu.EMU_DIR, "build/emu_api"])
+    r = subprocess.run([emu.EMU_DIR + "/build/emu_api"], capture_output=True, text=True, timeout=900,
+                       env={"ASAN_OPTIONS": "detect_leaks=1", "UBSAN_OPTIONS": "print_stacktrace=1"})
+    assert r.returncode == 0 and "emu_api ok" in r.stdout, r.stdout[-3000:] + r.stderr[-6000:]
+
+
 @pytest.mark.parametrize("name", golden_names())
 def test_emulated_kernels_reproduce_golden(emu, tmp_path, name):
     data, cam, params, rgba, hit, counters = load_golden(name)
