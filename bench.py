@@ -379,13 +379,24 @@ def scene_spp(sub):
     return rt.samples_per_pixel(sub)
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip() + f" ({os.cpu_count()} logical CPUs visible)"
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(data, params, threads):
     """The CPU oracle (FP64 restatement of the reference) on a bounded sample of the same workload:
     a centre window of the same frame, same scene, same spp."""
     import oracle
     from raytracer_amd import scenes
     W, H = params.width, params.height
-    ww, wh = min(W - 1, 512), min(H - 1, 288)
+    ww, wh = min(W - 1, 1024), min(H - 1, 512)
     x0, y0 = (W - 1 - ww) // 2, (H - 1 - wh) // 2
     win = (x0, y0, x0 + ww, y0 + wh)
     p = scenes.make_params(W, H, params.pixel_subdivision, tuple(params.ambient), window=win)
@@ -394,8 +405,8 @@ def cpu_baseline(data, params, threads):
     _, _, cnt = oracle.render(data, cam, p, want_hit_ids=False, threads=threads)
     dt = time.perf_counter() - t0
     rays = cnt["samples"] + cnt["rays_reflection"] + cnt["rays_shadow"]
-    # the reference itself is single-threaded (ViewController.swift:154): one thread on a sixteenth of the window
-    sw, sh = max(ww // 4, 1), max(wh // 4, 1)
+    # the reference itself is single-threaded (ViewController.swift:154): one thread on a twenty-fifth of the window
+    sw, sh = max(ww // 5, 1), max(wh // 5, 1)
     sx, sy = (W - 1 - sw) // 2, (H - 1 - sh) // 2
     p1 = scenes.make_params(W, H, params.pixel_subdivision, tuple(params.ambient), window=(sx, sy, sx + sw, sy + sh))
     t1 = time.perf_counter()
@@ -406,6 +417,7 @@ def cpu_baseline(data, params, threads):
         "value": round(rays / dt / 1e6, 4),
         "unit": "Mrays/s",
         "cores": threads,
+        "cpu_model": cpu_model(),
         "kind": "port",
         "sample": f"centre window {ww}x{wh} px of the same frame ({cnt['samples']} primary rays, "
                   f"{cnt['tri_tests']} ray-triangle tests, {dt:.1f} s); the window lies inside the mesh silhouette, "

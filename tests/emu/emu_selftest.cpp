@@ -1,6 +1,7 @@
 // Checks of the CPU stand-in for the HIP runtime itself (tests/emu/hip/hip_runtime.h): TEST INFRASTRUCTURE.
 //   emu_selftest ok        wave-level operations, divergent callers, barriers, atomics: prints "selftest ok"
 //   emu_selftest oob       a kernel writes one element past a hipMalloc'ed buffer: AddressSanitizer must end the run
+//   emu_selftest lds       a kernel writes one element past a __shared__ array: likewise
 //   emu_selftest barrier   two waves wait at different __syncthreads(): the emulator must end the run
 #include <hip/hip_runtime.h>
 
@@ -42,6 +43,13 @@ __global__ void k_lds(int* out) {
   out[blockIdx.x * 256 + t] = total + blockIdx.x;
 }
 
+__global__ void k_lds_oob(int* out) {
+  __shared__ int buf[64];
+  buf[threadIdx.x + 1] = (int)threadIdx.x;  // the last lane writes buf[64]
+  __syncthreads();
+  out[threadIdx.x] = buf[threadIdx.x];
+}
+
 __global__ void k_oob(int* p, int n) { p[threadIdx.x + n - 63] = 1; }  // the last lane writes p[n]
 
 __global__ void k_two_barriers(volatile int* out) {
@@ -70,6 +78,13 @@ int main(int argc, char** argv) {
     int* p;
     (void)hipMalloc(&p, 100 * sizeof(int));
     hipLaunchKernelGGL(k_oob, dim3(1), dim3(64), 0, nullptr, p, 100);
+    printf("no fault reported\n");
+    return 0;
+  }
+  if (!strcmp(what, "lds")) {
+    int* p;
+    (void)hipMalloc(&p, 64 * sizeof(int));
+    hipLaunchKernelGGL(k_lds_oob, dim3(1), dim3(64), 0, nullptr, p);
     printf("no fault reported\n");
     return 0;
   }

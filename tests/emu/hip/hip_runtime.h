@@ -58,7 +58,10 @@
 #define __forceinline__ inline
 #define __noinline__ __attribute__((noinline))
 #define __launch_bounds__(...)
-#define __shared__ static  // one workgroup runs at a time, so function-local statics are per-workgroup storage
+// One workgroup runs at a time, so function-local statics serve as its LDS.  They keep what the previous
+// workgroup left in them (as LDS does) and, being ordinary globals, they get AddressSanitizer's red zones:
+// an index past the end of a __shared__ array is reported.
+#define __shared__ static
 #define __constant__
 #define __align__(n) alignas(n)
 #define HIP_SYMBOL(x) (&(x))  // a file-scope __device__ variable is an ordinary global here

@@ -81,6 +81,8 @@ def test_emulator_selftest(emu):
     assert r.returncode == 0 and "selftest ok" in r.stdout, r.stdout + r.stderr
     r = subprocess.run([exe, "oob"], capture_output=True, text=True)
     assert r.returncode != 0 and "heap-buffer-overflow" in r.stderr and "k_oob" in r.stderr
+    r = subprocess.run([exe, "lds"], capture_output=True, text=True)
+    assert r.returncode != 0 and ("global-buffer-overflow" in r.stderr or "out of bounds" in r.stderr)
     r = subprocess.run([exe, "barrier"], capture_output=True, text=True)
     assert r.returncode != 0 and "different __syncthreads" in r.stderr
 
