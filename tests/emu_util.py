@@ -11,7 +11,8 @@ from raytracer_amd import _abi
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 EMU_DIR = os.path.join(HERE, "emu")
-EMU_BIN = os.path.join(EMU_DIR, "build", "emu_render")
+# EMU_RENDER_BIN: another build of the driver, e.g. the coverage build (tools/emu_coverage_report.py)
+EMU_BIN = os.environ.get("EMU_RENDER_BIN") or os.path.join(EMU_DIR, "build", "emu_render")
 
 
 def build(sanitize=True):

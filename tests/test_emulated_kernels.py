@@ -190,3 +190,60 @@ def test_emulated_random_scenes(emu, oracle_mod):
     import emu_fuzz
     with ThreadPoolExecutor(4) as pool:
         list(pool.map(lambda i: emu_fuzz.run_one(5, i, oracle_mod), range(8)))
+
+
+@pytest.mark.parametrize("form,level,size", [("B", 4, (40, 36, 0.5)), ("T", 4, (28, 24, 1.0)), ("B", 7, (12, 10, 1.0))])
+def test_emulated_many_triangles(emu, oracle_mod, tmp_path, form, level, size):
+    """5,120 triangles: the cone tree spans several workgroups of the packing kernel and its upper levels are merged
+    by the workgroup that finishes last.  327,680 triangles: six levels, and the list scan's compaction scans more
+    block counts than it has threads."""
+    data = scenes.mesh_scene(level=level, form=form, n_lights=3, bounding_sphere=oracle_mod.bounding_sphere)
+    cam = scenes.make_camera((0, 0, 4), (0, 0, -1), 10.0)
+    run_case(emu, oracle_mod, tmp_path, data, [cam, cam], scenes.make_params(*size))
+
+
+@pytest.mark.parametrize("rays_per_lane", ["2", "8"])
+def test_emulated_other_rays_per_lane(emu, oracle_mod, tmp_path, rays_per_lane):
+    """RTMI_SEARCH_R selects the 2- and 8-rays-per-lane instantiations of both search kernels."""
+    env = {"RTMI_SEARCH_R": rays_per_lane}
+    cam = scenes.make_camera((0, 0, 4), (0, 0, -1), 10.0)
+    data_b = scenes.mesh_scene(level=3, form="B", n_lights=2, bounding_sphere=oracle_mod.bounding_sphere)
+    run_case(emu, oracle_mod, tmp_path / "B", data_b, [cam], scenes.make_params(37, 29, 0.5), env=env)
+    data_t = scenes.mesh_scene(level=2, form="T", n_lights=2)
+    run_case(emu, oracle_mod, tmp_path / "T", data_t, [cam], scenes.make_params(30, 22, 0.5), env=env)
+
+
+def lights_on_primary_rays(oracle_mod, cam, W, H, pixels):
+    """Light positions that the primary rays of `pixels` hit EXACTLY: with the camera at the origin, 4*d is
+    representable whenever d is, and (4*d - 0)/d is 4 in every component (Renderables.swift:80-91 asks for equal
+    quotients)."""
+    ul, u, v, ph, pv = oracle_mod.frame(cam, W, H)
+    out = []
+    for i, j in pixels:
+        d = np.array(oracle_mod.pixel_to_world(ul, u, v, ph, pv, float(i), float(j)))
+        d = d / np.sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2])
+        out.append(tuple(4.0 * d))
+    return out
+
+
+def light_hit_scene(oracle_mod):
+    W, H = 24, 20
+    cam = scenes.make_camera((0, 0, 0), (0.3, -0.2, -1.0), 2.0)
+    pixels = [(5, 7), (11, 9), (17, 3), (8, 15)]
+    locs = lights_on_primary_rays(oracle_mod, cam, W, H, pixels)
+    lights = np.concatenate([scenes.light(loc=loc, specular=(0.8,) * 3, diffuse=(0.5,) * 3) for loc in locs])
+    objects = np.concatenate([scenes.light_object(0), scenes.light_object(1), scenes.sphere_object((0.5, -0.3, -3.0), 0.8, 0),
+                              scenes.light_object(2), scenes.light_object(3)])
+    data = scenes.SceneData(lights=lights, materials=scenes.material(**scenes.VC_MATERIAL), objects=objects,
+                            triangles=np.zeros(0, scenes.TRI_DTYPE))
+    return data, cam, scenes.make_params(W, H, 1.0), pixels
+
+
+def test_emulated_primary_rays_hit_point_lights(emu, oracle_mod, tmp_path):
+    """PointLight as a member of `objects` (Renderables.swift:80-91): a hit without a normal, shaded with the ambient
+    term only (RayTracingFunctions.swift:199-202)."""
+    data, cam, params, pixels = light_hit_scene(oracle_mod)
+    _, o_hit, _ = oracle_mod.render(data, cam, params)
+    ids = {int(o_hit[j, i, 0]) for i, j in pixels}
+    assert ids <= {-2, -3, -5, -6} and len(ids) >= 3, ids  # the lights are hit (one may lie behind the sphere in list order)
+    run_case(emu, oracle_mod, tmp_path, data, [cam], params, searches=("tree",))
