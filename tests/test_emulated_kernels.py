@@ -12,6 +12,7 @@ import pytest
 
 import emu_util
 from golden_util import golden_names, load_golden
+from scene_cases import light_hit_scene
 from raytracer_amd import _abi, scenes, sharding
 
 SEARCHES = {"tree": _abi.RTMI_SEARCH_CONE_TREE, "scan": _abi.RTMI_SEARCH_LIST_SCAN}
@@ -211,32 +212,6 @@ def test_emulated_other_rays_per_lane(emu, oracle_mod, tmp_path, rays_per_lane):
     run_case(emu, oracle_mod, tmp_path / "B", data_b, [cam], scenes.make_params(37, 29, 0.5), env=env)
     data_t = scenes.mesh_scene(level=2, form="T", n_lights=2)
     run_case(emu, oracle_mod, tmp_path / "T", data_t, [cam], scenes.make_params(30, 22, 0.5), env=env)
-
-
-def lights_on_primary_rays(oracle_mod, cam, W, H, pixels):
-    """Light positions that the primary rays of `pixels` hit EXACTLY: with the camera at the origin, 4*d is
-    representable whenever d is, and (4*d - 0)/d is 4 in every component (Renderables.swift:80-91 asks for equal
-    quotients)."""
-    ul, u, v, ph, pv = oracle_mod.frame(cam, W, H)
-    out = []
-    for i, j in pixels:
-        d = np.array(oracle_mod.pixel_to_world(ul, u, v, ph, pv, float(i), float(j)))
-        d = d / np.sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2])
-        out.append(tuple(4.0 * d))
-    return out
-
-
-def light_hit_scene(oracle_mod):
-    W, H = 24, 20
-    cam = scenes.make_camera((0, 0, 0), (0.3, -0.2, -1.0), 2.0)
-    pixels = [(5, 7), (11, 9), (17, 3), (8, 15)]
-    locs = lights_on_primary_rays(oracle_mod, cam, W, H, pixels)
-    lights = np.concatenate([scenes.light(loc=loc, specular=(0.8,) * 3, diffuse=(0.5,) * 3) for loc in locs])
-    objects = np.concatenate([scenes.light_object(0), scenes.light_object(1), scenes.sphere_object((0.5, -0.3, -3.0), 0.8, 0),
-                              scenes.light_object(2), scenes.light_object(3)])
-    data = scenes.SceneData(lights=lights, materials=scenes.material(**scenes.VC_MATERIAL), objects=objects,
-                            triangles=np.zeros(0, scenes.TRI_DTYPE))
-    return data, cam, scenes.make_params(W, H, 1.0), pixels
 
 
 def test_emulated_primary_rays_hit_point_lights(emu, oracle_mod, tmp_path):

@@ -511,3 +511,13 @@ def test_render_device_into_torch_tensor(rt, pig_scene):
     torch.cuda.synchronize()
     sc.render_device(cam, params, t.data_ptr(), h.data_ptr())
     assert (t.cpu().numpy() == host).all() and (h.cpu().numpy() == hhit).all()
+
+
+def test_primary_rays_hit_point_lights(oracle_mod, rt):
+    """PointLight as a member of `objects` (Renderables.swift:80-91), placed so that four primary rays hit lights
+    exactly: a hit without a normal, shaded with the ambient term only (RayTracingFunctions.swift:199-202)."""
+    from scene_cases import light_hit_scene
+    data, cam, params, pixels = light_hit_scene(oracle_mod)
+    _, o_hit, _ = oracle_mod.render(data, cam, params)
+    assert len({int(o_hit[j, i, 0]) for i, j in pixels} & {-2, -3, -5, -6}) >= 3
+    assert_parity(oracle_mod, rt, data, cam, params)
