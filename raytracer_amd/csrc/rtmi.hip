@@ -2156,6 +2156,7 @@ static int search_rays_per_lane() {
   }();
   return r;
 }
+constexpr int MAX_FRAME_EDGE = 1 << 20;          // widest and tallest frame accepted, in pixels
 constexpr size_t MAX_BATCH_SAMPLES = 1u << 28;  // 256 Mi samples per batch (about 100 B of work buffers per sample)
 
 // Frames with more samples than this are rendered in several batches of whole pixel blocks.
@@ -2175,6 +2176,7 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
                               void* hit_dev) {
   if (!sc || !cam || !p || !rgba_dev) return RTMI_ERR_INVALID_ARGUMENT;
   if (p->width < 2 || p->height < 2) return RTMI_ERR_INVALID_ARGUMENT;
+  if (p->width > MAX_FRAME_EDGE || p->height > MAX_FRAME_EDGE) return RTMI_ERR_UNSUPPORTED;  // index arithmetic below is sized for this
   if (p->hit_policy != RTMI_HIT_LIST_ORDER) return RTMI_ERR_UNSUPPORTED;
   if (p->search != RTMI_SEARCH_CONE_TREE && p->search != RTMI_SEARCH_LIST_SCAN) return RTMI_ERR_INVALID_ARGUMENT;
   const bool use_tree = p->search == RTMI_SEARCH_CONE_TREE;
@@ -2598,6 +2600,7 @@ extern "C" int32_t rtmi_render(rtmi_scene* sc, const rtmi_camera* cam, const rtm
                                int32_t* hit_id_out, rtmi_counters* counters) {
   if (!sc || !p || !rgba_out) return RTMI_ERR_INVALID_ARGUMENT;
   if (p->width < 2 || p->height < 2) return RTMI_ERR_INVALID_ARGUMENT;
+  if (p->width > MAX_FRAME_EDGE || p->height > MAX_FRAME_EDGE) return RTMI_ERR_UNSUPPORTED;
   int spp = rtmi_samples_per_pixel(p->pixel_subdivision);
   if (spp < 0) return spp;
   HIP_TRY(hipSetDevice(sc->device));

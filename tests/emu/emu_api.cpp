@@ -165,6 +165,8 @@ int main() {
     rtmi_params bad = p;
     bad.width = 1;
     REQUIRE(rtmi_render_device(sc, &cam, &bad, frame, nullptr, nullptr) == RTMI_ERR_INVALID_ARGUMENT);
+    bad = p; bad.width = (1 << 20) + 1;
+    REQUIRE(rtmi_render_device(sc, &cam, &bad, frame, nullptr, nullptr) == RTMI_ERR_UNSUPPORTED);
     bad = p; bad.pixel_subdivision = 0.0;
     REQUIRE(rtmi_render_device(sc, &cam, &bad, frame, nullptr, nullptr) == RTMI_ERR_INVALID_ARGUMENT);
     bad = p; bad.x1 = 25;

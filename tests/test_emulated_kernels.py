@@ -222,3 +222,28 @@ def test_emulated_primary_rays_hit_point_lights(emu, oracle_mod, tmp_path):
     ids = {int(o_hit[j, i, 0]) for i, j in pixels}
     assert ids <= {-2, -3, -5, -6} and len(ids) >= 3, ids  # the lights are hit (one may lie behind the sphere in list order)
     run_case(emu, oracle_mod, tmp_path, data, [cam], params, searches=("tree",))
+
+
+DEGENERATE_CAMERAS = {
+    "zero_dir": ((0, 0, 4), (0, 0, 0), 10.0),              # normalize(-dir) is NaN: every direction is NaN, nothing is hit
+    "dir_parallel_to_up": ((0, -4, 4), (0, 1, -1), 10.0),  # up x n = 0 (RayTracingFunctions.swift:50-53)
+    "focal_zero": ((0, 0, 4), (0, 0, -1), 0.0),            # the image plane passes through the camera
+    "focal_negative": ((0, 0, -4), (0, 0, -1), -10.0),
+    "focal_huge": ((0, 0, 4), (0, 0, -1), 1e300),
+    "pos_nan": ((float("nan"), 0, 4), (0, 0, -1), 10.0),
+    "pos_inf": ((float("inf"), 0, 4), (0, 0, -1), 10.0),
+    "dir_huge": ((0, 0, 4), (0, 0, -1e200), 10.0),
+    "dir_tiny": ((0, 0, 4), (0, 0, -1e-200), 10.0),
+    "pos_far": ((0, 0, 4e15), (0, 0, -1), 4e15),           # FP32 filters see the scene as a point
+}
+
+
+@pytest.mark.parametrize("form", ["B", "T"])
+def test_emulated_degenerate_cameras(emu, oracle_mod, tmp_path, form):
+    """Cameras the reference would accept from its text fields and then render garbage (or trap) with: NaN and
+    infinite directions must not become addresses, and what is rendered must still equal the oracle's frame."""
+    data = scenes.mesh_scene(level=2, form=form, n_lights=2, bounding_sphere=oracle_mod.bounding_sphere)
+    if form == "B":
+        data.objects = np.concatenate([data.objects, scenes.sphere_object((0.5, 0.5, 1.0), 0.3, 0)])
+    cams = [scenes.make_camera(*c) for c in DEGENERATE_CAMERAS.values()]
+    run_case(emu, oracle_mod, tmp_path, data, cams, scenes.make_params(20, 16, 0.5))
