@@ -117,7 +117,8 @@ typedef enum {
  * (RayTracingFunctions.swift:170, WorldCoordinateSequence.swift:69-87).
  * pixel_subdivision is WorldCoordinateSequence.pixelSubdivision (1, 0.5, 0.25 ...).
  * The pixel window and the cyclic tile selection restrict WHICH of those pixels are
- * rendered; pixel->world scaling always uses the full-frame constants. */
+ * rendered; pixel->world scaling always uses the full-frame constants.
+ * Limits: 2 <= width, height <= 2^20 (larger: RTMI_ERR_UNSUPPORTED); at most 64 samples per pixel. */
 typedef struct {
   int32_t width;
   int32_t height;
