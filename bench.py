@@ -23,6 +23,8 @@ if ROOT not in sys.path:
 
 FLOPS_PER_TEST = 69            # reference triangle test with ray-independent terms hoisted
 PEAK_FP32_TFLOPS = 157.3       # MI355X vector FP32 (256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz)
+PEAK_HBM_GBPS = 8000.0         # MI355X HBM3E
+SHADE_BYTES_PER_HIT = 64       # algorithmic HBM bytes of the shading kernels per shaded hit (see the roofline object)
 PEAK_FP64_TFLOPS = 78.6        # MI355X vector FP64 (256 CU x 4 SIMD x 32 FLOP/clk x 2.4 GHz; v_fma_f64 measured at 73 TFLOP/s)
 
 
@@ -246,6 +248,13 @@ def main():
                 "flops_per_hit_algorithmic": flops_hit,
                 "hits_per_launch": hits,
                 "avg_launch_ms": round(ms_shade, 4),
+                # the same launch against the HBM roofline: per shaded hit the kernel reads its candidate entry (8 B),
+                # the ray's best list position (4 B) and direction (24 B) and writes hit id (4 B) and colour (24 B);
+                # triangles, planes, materials and lights are a few hundred KB and stay in cache
+                "hbm_view": {"algorithmic_bytes_per_hit": SHADE_BYTES_PER_HIT,
+                             "achieved": round(hits * SHADE_BYTES_PER_HIT / (ms_shade * 1e-3) / 1e9, 1) if ms_shade > 0 else 0.0,
+                             "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                             "frac": round(hits * SHADE_BYTES_PER_HIT / (ms_shade * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4) if ms_shade > 0 else 0.0},
                 "note": "achieved = shaded hits per launch x the FP64 operations of calculateLighting per hit (division, sqrt, "
                         "pow counted as 1) / launch time (HIP events on the library's stream).  An IEEE FP64 division costs "
                         "about 13 instructions on this ISA and a sqrt about 20, and the reference's arithmetic (3 divisions "
