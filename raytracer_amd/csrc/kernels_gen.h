@@ -1,0 +1,116 @@
+// kernels_gen.h -- part of rtmi.hip, which includes its parts in a fixed order (each relies on the ones before it).
+// K_gen (ray generation and the first sphere-like hit) and k_resolve_top.
+// Not a stand-alone header.
+// ---------------------------------------------------------------------------------------
+// k_gen: one thread per sample of the batch
+// ---------------------------------------------------------------------------------------
+// Outcome per sample (hit_id): -1 miss / unrendered; >= 0 triangle; <= -2 sphere-like object.
+// With no top-level triangle runs the sample is resolved here: a sphere or light hit goes to
+// the shade queue, a bounding-sphere hit to the child-search queue.  With top-level runs
+// every rendered sample goes on to the top-level triangle search, which resolves it.
+constexpr int GEN_ITERS = 8;  // samples per thread in k_gen; a workgroup covers 2048 consecutive samples
+
+__global__ void __launch_bounds__(256)
+k_gen(FrameConst fc, SceneDev sc, const int2* __restrict__ blocks, int nsamples, int* hit_id, double* dirs,
+      int* q_child, int* q_shade, int* q_top, DevCounters* cnt) {
+  // queue entries are staged in LDS and flushed with one global atomic per queue per workgroup
+  __shared__ int lq[3][256 * GEN_ITERS];
+  __shared__ int ln[3];
+  __shared__ int lbase[3];
+  if (threadIdx.x < 3) ln[threadIdx.x] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const bool has_top = sc.n_top_tris > 0;
+  for (int it = 0; it < GEN_ITERS; ++it) {
+    const int t = (blockIdx.x * GEN_ITERS + it) * 4 + wv;  // wave-uniform: the 64-sample group of this wave
+    const int s = (t << 6) + lane;
+    int x = 0, y = 0, kx = 0, ky = 0;
+    bool live = false;
+    if ((t << 6) < nsamples) {  // nsamples is a multiple of 64
+      int b;
+      group_coords(fc, t, &b, &kx, &ky);
+      live = pixel_coords(fc, blocks, b, lane, &x, &y);
+    }
+    int id = -1;
+    bool to_child = false, to_shade = false;
+    if (live && fc.n_genf > 0) {
+      // FP32 pre-test: a sample whose direction stays clear of every object's cone hits nothing,
+      // and none of the FP64 work below is needed for it (hit_id = -1, no direction stored)
+      const float* uc = fc.utab_f + (size_t)(x * fc.n1 + kx) * 3;
+      const float* vc = fc.vtab_f + (size_t)(y * fc.n1 + ky) * 3;
+      const float fx = fc.base_f[0] + uc[0] - vc[0], fy = fc.base_f[1] + uc[1] - vc[1], fz = fc.base_f[2] + uc[2] - vc[2];
+      const float dd = fx * fx + fy * fy + fz * fz;
+      bool maybe = false;
+      for (int o = 0; o < fc.n_genf && !maybe; ++o) {
+        const float4 gf = fc.genf[o];
+        const float qd = gf.x * fx + gf.y * fy + gf.z * fz;
+        maybe = gf.w <= 0.0f || (qd > 0.0f && !(qd * qd < gf.w * dd));
+      }
+      live = maybe;
+    }
+    if (live) {
+      d3 d = sample_dir(fc, x, y, kx, ky);
+      int obj = first_sphere_like(sc, rtx::ld3(fc.cam), d);
+      if (obj >= 0) {
+        id = -2 - obj;
+        if (sc.objects[obj].kind == RTMI_BOUNDING_SPHERE) to_child = true; else to_shade = true;
+      }
+      if (obj >= 0 || has_top) {  // kept for the FP64 decisions of the search and for shading
+        dirs[(size_t)s * 3 + 0] = d.x;
+        dirs[(size_t)s * 3 + 1] = d.y;
+        dirs[(size_t)s * 3 + 2] = d.z;
+      }
+    }
+    if (s < nsamples) hit_id[s] = id;
+    // with top-level triangle runs every live sample is resolved after their search
+    bool pred[3] = {!has_top && to_child, !has_top && to_shade, has_top && live};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      unsigned long long mask = __ballot(pred[q]);
+      if (mask) {
+        int leader = __ffsll((long long)mask) - 1;
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&ln[q], __popcll(mask));
+        base = __shfl(base, leader);
+        if (pred[q]) lq[q][base + __popcll(mask & ((1ull << lane) - 1ull))] = s;
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    int* gcount = threadIdx.x == 0 ? &cnt->q_child : (threadIdx.x == 1 ? &cnt->q_shade : &cnt->q_top);
+    lbase[threadIdx.x] = ln[threadIdx.x] ? atomicAdd(gcount, ln[threadIdx.x]) : 0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    int* gq = q == 0 ? q_child : (q == 1 ? q_shade : q_top);
+    for (int i = threadIdx.x; i < ln[q]; i += 256) gq[lbase[q] + i] = lq[q][i];
+  }
+}
+
+// After the top-level triangle search: combine the first sphere-like object (hit_id from
+// k_gen) with the first top-level triangle (tri_hit) by list position.
+__global__ void __launch_bounds__(256)
+k_resolve_top(SceneDev sc, const int* __restrict__ q_top, const int* __restrict__ nq_ptr, const int* __restrict__ tri_hit,
+              const int* __restrict__ tri_owner, int* hit_id, int* q_child, int* q_shade, DevCounters* cnt) {
+  int q = blockIdx.x * blockDim.x + threadIdx.x;
+  bool to_child = false, to_shade = false;
+  int s = -1;
+  if (q < *nq_ptr) {
+    s = checked(q_top[q], sc.n_samples, cnt, 14);
+    int id = hit_id[s];
+    int th = tri_hit[q];
+    if (th >= 0) th = checked(th, sc.n_tris, cnt, 15);
+    int obj = id <= -2 ? -2 - id : 0x7fffffff;
+    if (th >= 0 && tri_owner[th] < obj) { id = th; obj = -1; }
+    hit_id[s] = id;
+    if (id >= 0) to_shade = true;
+    else if (id <= -2) {
+      if (sc.objects[checked(obj, sc.n_objects, cnt, 16)].kind == RTMI_BOUNDING_SPHERE) to_child = true; else to_shade = true;
+    }
+  }
+  block_append(&cnt->q_child, q_child, to_child, s);
+  block_append(&cnt->q_shade, q_shade, to_shade, s);
+}

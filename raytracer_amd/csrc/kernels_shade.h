@@ -1,0 +1,310 @@
+// kernels_shade.h -- part of rtmi.hip, which includes its parts in a fixed order (each relies on the ones before it).
+// CalculateLighting: k_shade, k_shade_candidates; k_resolve.
+// Not a stand-alone header.
+// ---------------------------------------------------------------------------------------
+// k_shade: calculateLighting (RayTracingFunctions.swift:182-271) for every hit sample
+// ---------------------------------------------------------------------------------------
+struct RGBd {
+  double r, g, b;
+};
+
+// the two frame constants shading reads
+struct ShadeConst {
+  double cam[3];
+  double ambient[3];
+};
+
+// pow(base, exponent) of the specular term (RayTracingFunctions.swift:259), base in (0, 1].
+// For the usual small whole-number exponents (OBJ "Ns" values like 8) binary powering is used:
+// at most ceil(log2 n)+popcount roundings, i.e. a few ulp, far below what can change
+// UInt8(255 * c); every other exponent goes through the device pow().
+__device__ inline double spec_pow(double base, double e) {
+  if (e >= 1.0 && e <= 64.0 && e == floor(e)) {
+    int n = (int)e;
+    double r = 1.0, b = base;
+    bool first = true;
+    while (n) {
+      if (n & 1) { r = first ? b : r * b; first = false; }
+      n >>= 1;
+      if (n) b = b * b;
+    }
+    return r;
+  }
+  return pow(base, e);
+}
+
+// Number of lights with normalLightVectorDp > 0 (RayTracingFunctions.swift:227-232) at a hit whose
+// object has no material.  There the light loop adds nothing to the colour (:245), but every
+// such light still costs the reference one shadow ray (:236), which the counters report.  The
+// sign of dp(normalize(L), normalize(N)) equals the sign of dp(L, N) whenever |dp(L, N)| exceeds
+// 2^-40 |L|_1 |N|_1 (the rounding of the normalised form is below 2^-48); only inside that band
+// are the two normalisations evaluated.
+__device__ inline int count_facing_lights(const SceneDev& sc, d3 P, d3 n, bool n_unit) {
+  int c = 0;
+  const double n1 = fabs(n.x) + fabs(n.y) + fabs(n.z);
+  for (int li = 0; li < sc.n_lights; ++li) {
+    d3 L = rtx::sub(rtx::ld3(sc.lights[li].loc), P);
+    double sdp = rtx::dp(L, n);
+    double band = 9.094947017729282e-13 * ((fabs(L.x) + fabs(L.y) + fabs(L.z)) * n1);
+    if (sdp > band) { ++c; continue; }
+    if (sdp < -band) continue;
+    d3 nn = n_unit ? n : rtx::normalize(n);
+    if (rtx::dp(rtx::normalize(L), nn) > 0) ++c;
+  }
+  return c;
+}
+
+template <bool REFLECT, bool HAS_TOP>
+__device__ RGBd calculate_lighting(const SceneDev& sc, const TopTreeRef& tt, const ShadeConst& fc, const Hit& is, d3 camera,
+                                   unsigned long long* n_refl, unsigned long long* n_shadow,
+                                   unsigned long long* n_tests, unsigned long long* n_elided) {
+  d3 surface_point = is.P;
+  RGBd I = {0.0, 0.0, 0.0};
+  const bool has_material = is.material >= 0;
+  rtmi_material mat;
+  if (has_material) {
+    mat = sc.materials[is.material];
+    // intensityMultiplier = ambientLight; intensityMultiplier.scale(material.ambient)  RTF:193-196
+    I.r = mat.Ka[0] * fc.ambient[0];
+    I.g = mat.Ka[1] * fc.ambient[1];
+    I.b = mat.Ka[2] * fc.ambient[2];
+  }
+  if (!is.has_normal) return I;  // RTF:199-202
+  if (!REFLECT && !has_material) {
+    // nothing below can change I (= 0); only the shadow rays are counted
+    int c = count_facing_lights(sc, surface_point, is.n, is.n_unit);
+    *n_shadow += c;
+    *n_elided += c;
+    return I;
+  }
+  d3 normal = is.n;
+  // RTF:204; only the reflection direction and the specular term read it
+  d3 surface_to_camera = rtx::mk(0.0, 0.0, 0.0);
+  if (REFLECT || has_material) surface_to_camera = rtx::normalize(rtx::sub(camera, surface_point));
+
+  if constexpr (REFLECT) {  // RTF:207-224
+    d3 incident = rtx::neg(surface_to_camera);
+    d3 reflection = rtx::sub(incident, rtx::smul(2 * rtx::dp(incident, normal), normal));
+    RGBd contribution = {0.0, 0.0, 0.0};
+    Hit rh;
+    bool anb;
+    *n_refl += 1;
+    if (trace_top_secondary<HAS_TOP>(sc, tt, surface_point, reflection, true, &rh, &anb, n_tests)) {
+      contribution = calculate_lighting<false, HAS_TOP>(sc, tt, fc, rh, surface_point, n_refl, n_shadow, n_tests, n_elided);
+    }
+    I.r = I.r + contribution.r;
+    I.g = I.g + contribution.g;
+    I.b = I.b + contribution.b;
+  }
+
+  if (!has_material) {  // the light loop adds nothing (RTF:245); count its shadow rays
+    int c = count_facing_lights(sc, surface_point, normal, true);
+    *n_shadow += c;
+    *n_elided += c;
+    I.r = rtx::clamp01(I.r); I.g = rtx::clamp01(I.g); I.b = rtx::clamp01(I.b);  // RTF:269
+    return I;
+  }
+#pragma nounroll
+  for (int li = 0; li < sc.n_lights; ++li) {  // RTF:226-268
+    const rtmi_light& light = sc.lights[li];
+    d3 point_to_light = rtx::normalize(rtx::sub(rtx::ld3(light.loc), surface_point));
+    double ndl = rtx::dp(point_to_light, normal);
+    if (ndl <= 0) continue;
+    Hit dummy;
+    bool anb = false;
+    *n_shadow += 1;
+    trace_top_secondary<HAS_TOP>(sc, tt, surface_point, point_to_light, false, &dummy, &anb, n_tests);
+    if (anb) continue;           // RTF:241
+    if (!has_material) continue; // RTF:245
+    double lr = light.diffuse[0], lg = light.diffuse[1], lb = light.diffuse[2];
+    lr = ndl * lr; lg = ndl * lg; lb = ndl * lb;                    // scale(normalLightVectorDp)
+    lr = mat.Kd[0] * lr; lg = mat.Kd[1] * lg; lb = mat.Kd[2] * lb;  // scale(material.diffuse)
+    I.r = I.r + lr; I.g = I.g + lg; I.b = I.b + lb;
+    d3 light_reflection = rtx::normalize(rtx::sub(rtx::smul(2 * ndl, normal), point_to_light));  // RTF:251
+    double rv = rtx::dp(light_reflection, surface_to_camera);
+    if (rv <= 0) continue;  // RTF:255-257
+    double specular_term = spec_pow(rv, mat.Ns);  // RTF:259
+    double sr = light.specular[0], sg = light.specular[1], sb = light.specular[2];
+    sr = specular_term * sr; sg = specular_term * sg; sb = specular_term * sb;
+    sr = mat.Ks[0] * sr; sg = mat.Ks[1] * sg; sb = mat.Ks[2] * sb;
+    sr = rtx::clamp01(sr); sg = rtx::clamp01(sg); sb = rtx::clamp01(sb);  // RTF:263
+    I.r = I.r + sr; I.g = I.g + sg; I.b = I.b + sb;
+  }
+  I.r = rtx::clamp01(I.r); I.g = rtx::clamp01(I.g); I.b = rtx::clamp01(I.b);  // RTF:269
+  return I;
+}
+
+// Work tallies of a shading lane, summed per wave at the end of the kernel.
+struct ShadeTally {
+  unsigned long long n_refl = 0, n_shadow = 0, n_hit = 0, n_tests = 0, n_elided = 0;
+};
+
+__device__ inline void shade_tally_flush(DevCounters* cnt, const ShadeTally& t) {
+  wave_count(cnt, C_HITS, t.n_hit);
+  wave_count(cnt, C_REFL, t.n_refl);
+  wave_count(cnt, C_SHADOW, t.n_shadow);
+  wave_count(cnt, C_TESTS_SECONDARY, t.n_tests);
+  wave_count(cnt, C_SHADOW_ELIDED, t.n_elided);
+}
+
+// Shade sample s whose primary ray (direction d) hit `id` (triangle index, or -2 - object index);
+// t_tri is the triangle's intersection parameter.
+template <bool HAS_TOP>
+__device__ __forceinline__ void shade_sample(const ShadeConst& fc, const SceneDev& sc, const TopTreeRef& tt, int s, d3 d,
+                                             int id, double t_tri, double* rgb, ShadeTally* tl) {
+  d3 cam = rtx::ld3(fc.cam);
+  Hit h;
+  bool ok = false;
+  if (id >= 0) {
+    const rtmi_triangle& tr = sc.tris[id];
+    const TriPlane pl = sc.planes[id];
+    // the search already decided this hit with Triangle.intersections; rebuild its point
+    // exactly as Renderables.swift:153 does: origin + intersectionParameter * direction
+    ok = true;
+    h.t = t_tri;
+    h.P = rtx::add(cam, rtx::smul(h.t, d));
+    h.n = rtx::mk(pl.nx, pl.ny, pl.nz);
+    h.has_normal = 1;
+    h.n_unit = 1;
+    h.material = tr.material;
+    h.id = id;
+  } else {
+    const rtmi_object& ob = sc.objects[-2 - id];
+    if (ob.kind == RTMI_LIGHT) {
+      ok = rtx::light_hit(rtx::ld3(sc.lights[ob.first].loc), cam, d, &h.t, &h.P);
+      h.has_normal = 0;
+      h.n_unit = 1;
+      h.material = -1;
+    } else {
+      ok = rtx::sphere_first(rtx::ld3(ob.center), ob.radius, cam, d, &h.t, &h.P, &h.n);
+      h.has_normal = 1;
+      h.n_unit = 1;
+      h.material = ob.material;
+    }
+    h.id = id;
+  }
+  RGBd c = {0.0, 0.0, 0.0};
+  if (ok) {
+    tl->n_hit += 1;
+    c = calculate_lighting<true, HAS_TOP>(sc, tt, fc, h, cam, &tl->n_refl, &tl->n_shadow, &tl->n_tests, &tl->n_elided);
+  }
+  rgb[(size_t)s * 3 + 0] = c.r;
+  rgb[(size_t)s * 3 + 1] = c.g;
+  rgb[(size_t)s * 3 + 2] = c.b;
+}
+
+// HAS_TOP: the scene lists triangles at top level, so secondary rays scan them (the code of
+// that scan is left out of the instantiation for scenes without such runs).
+template <bool HAS_TOP>
+__global__ void __launch_bounds__(256)
+k_shade(ShadeConst fc, SceneDev sc, TopTreeArgs ta, const f2* __restrict__ trec, const float* __restrict__ gst2,
+        const int* __restrict__ tslot_pos, const double* __restrict__ dirs,
+        const double* __restrict__ tval, const int* __restrict__ q_shade,
+        const int* __restrict__ nq_ptr, const int* __restrict__ hit_id, double* rgb, DevCounters* cnt) {
+  const TopTreeRef tt = make_top_tree(ta, trec, gst2, tslot_pos);
+  ShadeTally tl;
+  const int nq = *nq_ptr;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
+    int s = checked(q_shade[q], sc.n_samples, cnt, 17);
+    d3 d = rtx::mk(dirs[(size_t)s * 3 + 0], dirs[(size_t)s * 3 + 1], dirs[(size_t)s * 3 + 2]);
+    int id = hit_id[s];
+    // a triangle index or -2 - object index, both about to be used as such
+    if (id >= 0) id = checked(id, sc.n_tris, cnt, 18);
+    else id = -2 - checked(-2 - id, sc.n_objects, cnt, 19);
+    shade_sample<HAS_TOP>(fc, sc, tt, s, d, id, id >= 0 ? tval[s] : 0.0, rgb, &tl);
+  }
+  shade_tally_flush(cnt, tl);
+}
+
+// The cone tree's last stage for the children of a bounding object: one lane per candidate
+// (grid-stride over the NSLOT lists, like k_search_exact).  The candidate whose list position is
+// the ray's lowest hit -- k_search_exact has settled that -- is the ray's intersection: its
+// triangle index goes to hit_id and the sample is shaded here, without a detour through the
+// shade queue.  t is evaluated once more (the same two operations, the same value).  Samples
+// without a hit keep the bounding object's marker in hit_id; k_resolve reads that as a miss.
+template <bool HAS_TOP>
+__global__ void __launch_bounds__(256, HAS_TOP ? 2 : 4)
+k_shade_candidates(ShadeConst fc, SceneDev sc, TopTreeArgs ta, const f2* __restrict__ trec, const float* __restrict__ gst2,
+                   const int* __restrict__ tslot_pos, const SearchArgs* __restrict__ ap, double* rgb, int par) {
+  DevCounters* cnt = ap->cnt;
+  const TopTreeRef tt = make_top_tree(ta, trec, gst2, tslot_pos);
+  ShadeTally tl;
+  if (!cnt->overflow) {
+    const int list = blockIdx.x & (NSLOT - 1), part = blockIdx.x / NSLOT, parts = gridDim.x / NSLOT;
+    const int list_cap = ap->cand_cap / NSLOT;
+    const int n = min(cnt->cand_n[par][list][0], list_cap);
+    const int2* cand = ap->cand + (size_t)list * list_cap;
+    const double* dirs = ap->dirs;
+    // as in k_search_exact: the next step's entry and what hangs on it are fetched one step ahead
+    const int stride = parts * blockDim.x;
+    const int* group = ap->group;
+    const int* best_pos = ap->best_pos;
+    int i = part * blockDim.x + threadIdx.x;
+    const int n_group = ap->n_group, n_samples = ap->n_samples, n_tris = ap->n_tris;
+    auto entry = [&](int k) {  // candidate k with both indices range-checked
+      int2 e = cand[k];
+      e.x = checked(e.x, n_samples, cnt, 9);
+      e.y = checked(e.y, n_group, cnt, 10);
+      return e;
+    };
+    int2 c = i < n ? entry(i) : make_int2(0, 0);
+    int ti = i < n ? checked(group[c.y], n_tris, cnt, 11) : 0;
+    int bp = i < n ? best_pos[c.x] : 0;
+    while (i < n) {
+      const int inext = i + stride;
+      const int2 cn = inext < n ? entry(inext) : c;
+      const int tin = checked(group[cn.y], n_tris, cnt, 11);
+      const int bpn = best_pos[cn.x];
+      const int s = c.x;
+      if (bp == c.y) {  // else another triangle of this ray is listed earlier, or the pair was no hit
+        const double* dp = dirs + (size_t)s * 3;
+        const d3 d = rtx::mk(dp[0], dp[1], dp[2]);
+        const double tv = rtx::tri_t(sc.planes[ti], rtx::ld3(fc.cam), d);  // k_search_exact accepted this pair
+        ap->hit_id[s] = ti;
+        shade_sample<HAS_TOP>(fc, sc, tt, s, d, ti, tv, rgb, &tl);
+      }
+      c = cn;
+      ti = tin;
+      bp = bpn;
+      i = inext;
+    }
+  }
+  search_lists_retire(cnt, par);
+  shade_tally_flush(cnt, tl);
+}
+
+// ---------------------------------------------------------------------------------------
+// k_resolve: per pixel average and RGBA8 store (RayTracingFunctions.swift:105-111,
+// Utilities.swift:54-65)
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_resolve(FrameConst fc, const int2* __restrict__ blocks, int npix, const int* __restrict__ hit_id,
+          const double* __restrict__ rgb, const rtmi_object* __restrict__ objects, int n_objects, DevCounters* cnt,
+          unsigned char* rgba, int* hit_out) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npix) return;
+  int b = p >> 6, pix = p & (BLK_PIX - 1);
+  int x, y;
+  if (!pixel_coords(fc, blocks, b, pix, &x, &y)) return;
+  double cr = 0.0, cg = 0.0, cb = 0.0;  // cumulative = RGB(0,0,0), Utilities.swift:56
+  for (int q = 0; q < fc.spp; ++q) {
+    int s = ((b * fc.spp + q) << 6) + pix;
+    int id = hit_id[s];
+    // a bounding object's marker that no child hit has replaced: the ray hit nothing (RTF:86-93)
+    if (id <= -2 && objects[checked(-2 - id, n_objects, cnt, 20)].kind == RTMI_BOUNDING_SPHERE) id = -1;
+    double r = 0.0, g = 0.0, bl = 0.0;  // RGB.black for a miss
+    if (id != -1) {
+      r = rgb[(size_t)s * 3 + 0];
+      g = rgb[(size_t)s * 3 + 1];
+      bl = rgb[(size_t)s * 3 + 2];
+    }
+    cr = cr + r; cg = cg + g; cb = cb + bl;
+    if (hit_out) hit_out[((size_t)y * fc.W + x) * fc.spp + q] = id;
+  }
+  double factor = 1 / (double)fc.spp;  // Utilities.swift:61-62
+  double ar = factor * cr, ag = factor * cg, ab = factor * cb;
+  size_t first_byte = (size_t)4 * fc.W * y + (size_t)x * 4;  // RayTracingFunctions.swift:106-107
+  unsigned int px = (unsigned int)(unsigned char)(255 * ar) | ((unsigned int)(unsigned char)(255 * ag) << 8) |
+                    ((unsigned int)(unsigned char)(255 * ab) << 16) | (255u << 24);
+  *reinterpret_cast<unsigned int*>(rgba + first_byte) = px;  // R,G,B,255 in memory order (:108-111)
+}

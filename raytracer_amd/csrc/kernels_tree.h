@@ -1,0 +1,283 @@
+// kernels_tree.h -- part of rtmi.hip, which includes its parts in a fixed order (each relies on the ones before it).
+// The cone tree search (RTMI_SEARCH_CONE_TREE): k_search_tree, k_search_exact, k_search_finish.
+// Not a stand-alone header.
+// ---------------------------------------------------------------------------------------
+// the default search: cone tree (rtmi_tree.h) in three launches
+// ---------------------------------------------------------------------------------------
+//   k_search_tree    FP32 only: walks the tree once per wave and emits every (ray, triangle slot)
+//                    pair that passes the triangle's cone and edge tests -- the candidates
+//   k_search_exact   one lane per candidate: the FP64 reference-order test; a hit lowers the
+//                    ray's best list position (atomicMin)
+//   k_search_finish  one lane per ray: best list position -> triangle index, t, shade queue
+// Splitting the double-precision work off keeps the walk at a register count that allows eight
+// waves per SIMD (the walk is a chain of dependent scalar loads; occupancy hides their latency)
+// and runs the FP64 tests with all 64 lanes busy.
+constexpr int CAND_STAGE = 512;  // candidates a wave collects in LDS before it reserves global space
+
+// Evaluate one record of inner-node cones for the R rays of every lane; returns the mask of
+// children that some ray of the wave passes, or that are flagged "always descend".
+template <int R>
+__device__ __forceinline__ unsigned tree_eval(const f2* __restrict__ rp, const float (&dx)[R], const float (&dy)[R],
+                                              const float (&dz)[R]) {
+  f2 cur[12];
+#pragma unroll
+  for (int c = 0; c < 12; ++c) cur[c] = rp[c];
+  unsigned mask = reinterpret_cast<const unsigned*>(rp)[REC_ALWAYS];
+#pragma unroll
+  for (int pr = 0; pr < 4; ++pr) {
+    f2 q[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { f2 X = {dx[r], dx[r]}; q[r] = cur[pr * 3 + 0] * X; }
+#pragma unroll
+    for (int r = 0; r < R; ++r) { f2 Y = {dy[r], dy[r]}; q[r] = __builtin_elementwise_fma(cur[pr * 3 + 1], Y, q[r]); }
+#pragma unroll
+    for (int r = 0; r < R; ++r) { f2 Z = {dz[r], dz[r]}; q[r] = __builtin_elementwise_fma(cur[pr * 3 + 2], Z, q[r]); }
+    float ma = q[0].x, mb = q[0].y;  // fmaxf drops the NaN of absent rays
+#pragma unroll
+    for (int r = 1; r < R; ++r) { ma = __builtin_fmaxf(ma, q[r].x); mb = __builtin_fmaxf(mb, q[r].y); }
+    if (__any(ma >= 1.0f)) mask |= 1u << (2 * pr);
+    if (__any(mb >= 1.0f)) mask |= 2u << (2 * pr);
+  }
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)mask);
+}
+
+// Called by the last kernel of a tree search launch (any one workgroup's first NSLOT threads do
+// the work): add this launch's candidate counts to the frame total and clear the OTHER set of
+// list counters, which the launch before this one used and the next one will use.
+__device__ inline void search_lists_retire(DevCounters* cnt, int parity) {
+  if (blockIdx.x == 0 && threadIdx.x < NSLOT) {
+    atomicAdd(&cnt->cand_total, (unsigned long long)(unsigned int)cnt->cand_n[parity][threadIdx.x][0]);
+    cnt->cand_n[parity ^ 1][threadIdx.x][0] = 0;
+  }
+}
+
+// Hand the wave's staged candidates to its global list: one returning atomic per flush.
+__device__ __forceinline__ void cand_flush(const SearchArgs* ap, const int2* stage, int fill, int lane, int list, int parity) {
+  if (fill == 0) return;
+  DevCounters* cnt = ap->cnt;
+  const int list_cap = ap->cand_cap / NSLOT;
+  int base = 0;
+  if (lane == 0) base = atomicAdd(&cnt->cand_n[parity][list][0], fill);
+  base = __builtin_amdgcn_readfirstlane(base);
+  if (base + fill > list_cap || base < 0) {
+    if (lane == 0) cnt->overflow = 1;  // the caller renders this frame again with the list scan
+    return;
+  }
+  int2* cand = ap->cand + (size_t)list * list_cap + base;
+  for (int i = lane; i < fill; i += 64) cand[i] = stage[i];
+}
+
+// Each wave walks the tree depth first for its R*64 rays.  The walk is wave-uniform: `lvl`, the
+// record index `ri` and `masks` (one byte of children still to visit per level) live in scalar
+// registers.  Record (l, r) holds the cones of nodes 8r..8r+7 of level l; the children of node
+// (l, j) are record (l-1, j); level-0 nodes are triangle slots, and a level-0 record is not
+// pushed but evaluated per lane: every (ray, slot) pair that passes becomes a candidate.
+template <int R>
+__global__ void __launch_bounds__(256, 6)
+k_search_tree(const SearchArgs* __restrict__ ap, const f2* __restrict__ rec, const float* __restrict__ edge_all,
+              const int* __restrict__ slot_pos, int parity) {
+  __shared__ int2 stage_all[4][CAND_STAGE];
+  const int nq = *ap->nq_ptr;
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int base = wave * 64 * R;
+  if (base >= nq) return;  // no workgroup-wide synchronisation below: waves leave on their own
+  int2* stage = stage_all[threadIdx.x >> 6];
+
+  int sid[R];
+  float dx[R], dy[R], dz[R];
+  search_prologue<R>(ap, base, nq, lane, sid, dx, dy, dz);
+  {
+    int* best_pos = ap->best_pos;  // this launch decides these rays: no hit so far
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (sid[r] >= 0) best_pos[sid[r]] = 0x7fffffff;
+  }
+  unsigned n_leaf_rec = 0, n_node_rec = 0;
+  int fill = 0;
+
+  const int ltop = ap->tree.ltop, n_root = ap->tree.n_root;
+  // first record of each level, in scalar registers; the select chain is scalar code
+  const int o0 = ap->tree.rec_off[0], o1 = ap->tree.rec_off[1], o2 = ap->tree.rec_off[2], o3 = ap->tree.rec_off[3],
+            o4 = ap->tree.rec_off[4], o5 = ap->tree.rec_off[5], o6 = ap->tree.rec_off[6], o7 = ap->tree.rec_off[7];
+  static_assert(TREE_MAX_LEVELS == 8, "level_off lists eight levels");
+  auto level_off = [&](int lvl) {
+    return lvl == 1 ? o1 : lvl == 2 ? o2 : lvl == 3 ? o3 : lvl == 4 ? o4 : lvl == 5 ? o5 : lvl == 6 ? o6 : o7;
+  };
+  // Level-0 record `ri`: the triangle cones of slots 8*ri..8*ri+7 against every ray of the lane.
+  // A triangle that no ray of the wave passes costs three maxima and a vote; for the others the
+  // edge test follows at once, and what remains is a candidate.
+  const int n_slots = ap->tree.n_slots, n_records = ap->n_records;
+  auto leaf = [&](int ri) {
+    if ((unsigned)(ri * 8) >= (unsigned)n_slots) {  // only a defective record can lead here
+      ap->cnt->bug = 3;
+      return;
+    }
+    ++n_leaf_rec;
+    const f2* rp = rec + (size_t)(o0 + ri) * (REC_DWORDS / 2);
+    f2 cur[12];
+#pragma unroll
+    for (int c = 0; c < 12; ++c) cur[c] = rp[c];
+    const unsigned always = reinterpret_cast<const unsigned*>(rp)[REC_ALWAYS];  // wide triangles (NaN cones)
+    const float* edge = edge_all + (size_t)ri * (8 * EDGE_FLOATS);
+#pragma unroll
+    for (int pr = 0; pr < 4; ++pr) {
+      f2 q[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) { f2 X = {dx[r], dx[r]}; q[r] = cur[pr * 3 + 0] * X; }
+#pragma unroll
+      for (int r = 0; r < R; ++r) { f2 Y = {dy[r], dy[r]}; q[r] = __builtin_elementwise_fma(cur[pr * 3 + 1], Y, q[r]); }
+#pragma unroll
+      for (int r = 0; r < R; ++r) { f2 Z = {dz[r], dz[r]}; q[r] = __builtin_elementwise_fma(cur[pr * 3 + 2], Z, q[r]); }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int jj = pr * 2 + h;
+        float mq = h ? q[0].y : q[0].x;  // fmaxf drops the NaN of absent rays
+#pragma unroll
+        for (int r = 1; r < R; ++r) mq = __builtin_fmaxf(mq, h ? q[r].y : q[r].x);
+        if (!__any(mq >= 1.0f) && !((always >> jj) & 1u)) continue;
+        const float* m = edge + jj * EDGE_FLOATS;
+        const float m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3], m4 = m[4], m5 = m[5], m6 = m[6], m7 = m[7], m8 = m[8];
+        const int pos = checked(slot_pos[ri * 8 + jj], ap->n_group, ap->cnt, 4);  // the triangle's position in the group's list order
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const float qv = h ? q[r].y : q[r].x;
+          float s0 = __builtin_fmaf(m2, dz[r], __builtin_fmaf(m1, dy[r], m0 * dx[r]));
+          float s1 = __builtin_fmaf(m5, dz[r], __builtin_fmaf(m4, dy[r], m3 * dx[r]));
+          float s2 = __builtin_fmaf(m8, dz[r], __builtin_fmaf(m7, dy[r], m6 * dx[r]));
+          float e = __builtin_fmaxf(__builtin_fmaxf(s0, s1), s2);
+          // !(q < 1) also lets a NaN cone (wide triangle) through; absent rays are excluded by sid
+          const bool pass = !(qv < 1.0f) && sid[r] >= 0 && e <= 1.0f;
+          const unsigned long long bm = __ballot(pass);
+          if (bm == 0) continue;
+          const int n = __popcll(bm);
+          if (fill + n > CAND_STAGE) {
+            cand_flush(ap, stage, fill, lane, wave & (NSLOT - 1), parity);
+            fill = 0;
+            __builtin_amdgcn_wave_barrier();
+          }
+          if (pass) stage[fill + __popcll(bm & ((1ull << lane) - 1ull))] = make_int2(sid[r], pos);
+          fill += n;
+        }
+      }
+    }
+  };
+
+  if (ltop == 0) {
+    for (int t = 0; t < n_root; ++t) leaf(t);
+  } else {
+    for (int t = 0; t < n_root; ++t) {
+      int lvl = ltop, ri = t;
+      unsigned long long masks;
+      {
+        unsigned m = tree_eval<R>(rec + (size_t)checked(level_off(lvl) + ri, n_records, ap->cnt, 5) * (REC_DWORDS / 2), dx, dy, dz);
+        masks = (unsigned long long)m << (8 * lvl);
+        ++n_node_rec;
+      }
+      for (;;) {
+        const unsigned cur = (unsigned)(masks >> (8 * lvl)) & 0xffu;
+        if (cur == 0) {
+          if (lvl == ltop) break;
+          ++lvl;
+          ri >>= 3;
+          continue;
+        }
+        const int c = __builtin_ctz(cur);
+        masks &= ~(1ull << (8 * lvl + c));
+        const int child = ri * 8 + c;
+        if (lvl == 1) {
+          leaf(child);
+        } else {
+          --lvl;
+          ri = child;
+          unsigned m = tree_eval<R>(rec + (size_t)checked(level_off(lvl) + ri, n_records, ap->cnt, 5) * (REC_DWORDS / 2), dx, dy, dz);
+          masks |= (unsigned long long)m << (8 * lvl);
+          ++n_node_rec;
+        }
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  cand_flush(ap, stage, fill, lane, wave & (NSLOT - 1), parity);
+
+  // work counters: (ray, triangle) cone tests at leaf level, (ray, node) tests above it
+  int active = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) active += __popcll(__ballot(sid[r] >= 0));
+  DevCounters* cnt = ap->cnt;
+  wave_count(cnt, C_TESTS_PRIMARY, lane == 0 ? 8ull * n_leaf_rec * (unsigned long long)active : 0ull);
+  wave_count(cnt, C_NODE_TESTS, lane == 0 ? 8ull * n_node_rec * (unsigned long long)active : 0ull);
+}
+
+// One lane per candidate: the reference's own arithmetic in FP64; a hit competes for the ray's
+// lowest list position.  Workgroup w serves candidate list w & 63 together with the other
+// workgroups of that residue (the grid is a multiple of 64 workgroups).
+__global__ void __launch_bounds__(256)
+k_search_exact(const SearchArgs* __restrict__ ap, int parity) {
+  const DevCounters* cnt = ap->cnt;
+  unsigned int n_exact = 0;
+  if (!cnt->overflow) {  // after an overflow the lists are incomplete and the frame is rendered again
+    const int list = blockIdx.x & (NSLOT - 1), part = blockIdx.x / NSLOT, parts = gridDim.x / NSLOT;
+    const int list_cap = ap->cand_cap / NSLOT;
+    const int n = min(cnt->cand_n[parity][list][0], list_cap);
+    const int2* cand = ap->cand + (size_t)list * list_cap;
+    const double* dirs = ap->dirs;
+    const d3 o = rtx::ld3(ap->cam);
+    // The entry of the NEXT step is fetched (with the triangle index it leads to) before the
+    // current one is evaluated: a step begins with a chain of dependent loads, and this way the
+    // chain of step k+1 runs under the arithmetic of step k.
+    const int stride = parts * blockDim.x;
+    const int* group = ap->group;
+    int i = part * blockDim.x + threadIdx.x;
+    DevCounters* wcnt = ap->cnt;
+    const int n_group = ap->n_group, n_samples = ap->n_samples, n_tris = ap->n_tris;
+    auto entry = [&](int k) {  // candidate k with both indices range-checked
+      int2 e = cand[k];
+      e.x = checked(e.x, n_samples, wcnt, 6);
+      e.y = checked(e.y, n_group, wcnt, 7);
+      return e;
+    };
+    int2 c = i < n ? entry(i) : make_int2(0, 0);
+    int ti = i < n ? checked(group[c.y], n_tris, wcnt, 8) : 0;
+    while (i < n) {
+      const int inext = i + stride;
+      const int2 cn = inext < n ? entry(inext) : c;
+      const int tin = checked(group[cn.y], n_tris, wcnt, 8);
+      const int s = c.x, pos = c.y;
+      const double* dp = dirs + (size_t)s * 3;
+      const rtmi_triangle& tr = ap->tris[ti];
+      d3 P;
+      double tv;
+      n_exact += 1;
+      if (rtx::tri_hit(rtx::ld3(tr.v[0]), rtx::ld3(tr.v[1]), rtx::ld3(tr.v[2]), ap->planes[ti], o,
+                       rtx::mk(dp[0], dp[1], dp[2]), &tv, &P))
+        atomicMin(&ap->best_pos[s], pos);
+      c = cn;
+      ti = tin;
+      i = inext;
+    }
+  }
+  wave_count(ap->cnt, C_EXACT, (unsigned long long)n_exact);
+}
+
+// Top-level runs only (mode 1): one lane per ray of the queue, lowest list position that was
+// hit -> triangle index in tri_hit[q] for k_resolve_top, and the hit's t.
+__global__ void __launch_bounds__(256)
+k_search_finish(const SearchArgs* __restrict__ ap, int parity) {
+  const int nq = *ap->nq_ptr;
+  search_lists_retire(ap->cnt, parity);
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  const int s = checked(ap->queue[q], ap->n_samples, ap->cnt, 12);
+  int ti = -1;
+  const int pos = ap->best_pos[s];
+  // After a candidate-list overflow the frame is rendered again; all this launch must do then is
+  // leave valid indices behind.  The range check keeps any unexpected value from becoming an address.
+  if (!ap->cnt->overflow && (unsigned)pos < (unsigned)ap->n_group) {
+    ti = checked(ap->group[pos], ap->n_tris, ap->cnt, 13);
+    const double* dp = ap->dirs + (size_t)s * 3;
+    const double tv = rtx::tri_t(ap->planes[ti], rtx::ld3(ap->cam), rtx::mk(dp[0], dp[1], dp[2]));
+    ap->tval[s] = tv;  // the hit point is origin + t*direction; shading rebuilds it
+  }
+  ap->tri_hit[q] = ti;
+}

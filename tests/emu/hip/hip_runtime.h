@@ -1,6 +1,6 @@
 // CPU stand-in for <hip/hip_runtime.h>: TEST INFRASTRUCTURE ONLY.
 //
-// The kernels of raytracer_amd/csrc/rtmi.hip are compiled unchanged as host C++ against this header and run one
+// The kernels of raytracer_amd/csrc/rtmi.hip (and the kernels_*.h parts it includes) are compiled unchanged as host C++ against this header and run one
 // workgroup at a time, every work-item as a fiber on its own stack, so that AddressSanitizer and a
 // debugger see each "device" access.  What it checks that a GPU run cannot report:
 //   * every access to a hipMalloc'ed buffer is bounds-checked (the buffers are malloc blocks; ASan's

@@ -2,7 +2,7 @@
 
 The GPU kernels nominate (ray, triangle) pairs with FP32 tests and decide them in FP64; hit ids are
 exact only if no FP32 test ever rejects a pair the reference accepts.  This file restates the
-operand construction of k_pack_write / k_pack_tree / merge_cones / tree_sphere_records (rtmi.hip,
+operand construction of k_pack_write / k_pack_tree / merge_cones / tree_sphere_records (kernels_prepare.h,
 rtmi_tree.h) in numpy and evaluates the tests the way the kernels do (float32 operands, fused
 multiply-add chains), for rays the ORACLE says hit: every such ray must pass the triangle's cone,
 the cone of every ancestor, the edge test, and (for arbitrary origins) the bounding spheres.

@@ -44,7 +44,7 @@ def main():
         func, where = lines[0], lines[1]
         m = re.match(r"(.*):(\d+):(\d+)$", where)
         fname, lineno = (os.path.basename(m.group(1)), int(m.group(2))) if m else ("?", 0)
-        if fname not in ("rtmi.hip", "rtmi_tree.h", "rtmi_exact.h"):
+        if fname not in ("rtmi.hip", "rtmi_tree.h", "rtmi_exact.h") and not fname.startswith("kernels_"):
             continue
         func = re.sub(r"\(.*", "", func)
         e = per_func[func]
@@ -59,6 +59,7 @@ def main():
         host_from = host_code_starts()
         per_func = {f: e for f, e in per_func.items()
                     if (e["file"] == "rtmi.hip" and e["first_line"] < host_from) or e["file"] in ("rtmi_exact.h",)
+                    or e["file"].startswith("kernels_")
                     or (e["file"] == "rtmi_tree.h" and (f.startswith("k_") or f in ("merge_cones", "rec_entry", "store_cone") or "k_pack_tree" in f))}
     tot = sum(e["edges"] for e in per_func.values())
     got = sum(e["ran"] for e in per_func.values())
