@@ -79,3 +79,18 @@ def test_second_restatement_agrees_on_random_soup(oracle_mod):
                               scenes.triangles_object(35, 25), scenes.light_object(2)])
     data = scenes.SceneData(lights=lights, materials=mats, objects=objects, triangles=tris)
     agree(oracle_mod, data, scenes.make_camera((0.2, 0.3, 4), (0, -0.05, -1), 7.0), scenes.make_params(18, 14, 0.5))
+
+
+def test_second_restatement_agrees_on_generated_scenes(oracle_mod):
+    """Scenes of the emulated-kernel fuzzer (degenerate and non-finite triangles, empty groups, spheres that do not
+    bound, cameras inside the geometry), whole small frames."""
+    import emu_fuzz
+    done = 0
+    for i in range(40):
+        data, cam, params = emu_fuzz.random_case(21, i)
+        if len(data.triangles) > 150:
+            continue
+        p = scenes.make_params(min(params.width, 10), min(params.height, 8), params.pixel_subdivision, tuple(params.ambient))
+        agree(oracle_mod, data, cam, p)
+        done += 1
+    assert done >= 20
