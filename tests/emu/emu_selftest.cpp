@@ -2,6 +2,8 @@
 //   emu_selftest ok        wave-level operations, divergent callers, barriers, atomics: prints "selftest ok"
 //   emu_selftest oob       a kernel writes one element past a hipMalloc'ed buffer: AddressSanitizer must end the run
 //   emu_selftest lds       a kernel writes one element past a __shared__ array: likewise
+//   emu_selftest race      (race-detection build only) LDS written and read across waves without a barrier:
+//                          ThreadSanitizer must report a data race
 //   emu_selftest barrier   two waves wait at different __syncthreads(): the emulator must end the run
 #include <hip/hip_runtime.h>
 
@@ -50,6 +52,14 @@ __global__ void k_lds_oob(int* out) {
   out[threadIdx.x] = buf[threadIdx.x];
 }
 
+// Work-items of one workgroup exchange a value through LDS without a barrier in between.
+__global__ void k_race(int* out) {
+  __shared__ int fill;
+  if (threadIdx.x == 0) fill = 7;
+  // (a __syncthreads() belongs here)
+  out[threadIdx.x] = fill + (int)threadIdx.x;
+}
+
 __global__ void k_oob(int* p, int n) { p[threadIdx.x + n - 63] = 1; }  // the last lane writes p[n]
 
 __global__ void k_two_barriers(volatile int* out) {
@@ -86,6 +96,14 @@ int main(int argc, char** argv) {
     (void)hipMalloc(&p, 64 * sizeof(int));
     hipLaunchKernelGGL(k_lds_oob, dim3(1), dim3(64), 0, nullptr, p);
     printf("no fault reported\n");
+    return 0;
+  }
+  if (!strcmp(what, "race")) {
+    int* p;
+    (void)hipMalloc(&p, 128 * sizeof(int));
+    hipLaunchKernelGGL(k_race, dim3(1), dim3(128), 0, nullptr, p);
+    (void)hipFree(p);
+    printf("race kernel ran\n");
     return 0;
   }
   if (!strcmp(what, "barrier")) {

@@ -50,6 +50,24 @@
 #ifdef EMU_ASAN
 #include <sanitizer/common_interface_defs.h>
 #endif
+#if defined(__has_feature)
+#if __has_feature(thread_sanitizer)
+#define EMU_TSAN 1
+#endif
+#endif
+// Race detection (make -C tests/emu tsan).  Every work-item is a ThreadSanitizer fiber.  Switches between the
+// scheduler and a waiting work-item carry no ordering; ordering comes only from what orders work-items on a GPU:
+// a wave-level operation (among the lanes that take part), __syncthreads() (the workgroup), atomics, and the end
+// of a workgroup (workgroups run one after the other here, so accesses of DIFFERENT workgroups are never
+// reported).  What is reported: two work-items of one workgroup that touch the same LDS or global location, one
+// of them writing, with none of the above in between -- also lanes of one wave that rely on executing in lock
+// step without saying so (a wave_barrier between the store and the load is what says so).
+#ifdef EMU_TSAN
+#include <sanitizer/tsan_interface.h>
+#define EMU_NO_TSAN __attribute__((no_sanitize("thread")))
+#else
+#define EMU_NO_TSAN
+#endif
 
 // ---- language ---------------------------------------------------------------------------
 #define __global__
@@ -167,6 +185,7 @@ struct Lane {
   int nchain;
   void* fake_stack;
   void* top_frame;  // frame of the fiber's entry function: where the position chain ends
+  void* tsan_fiber;
 };
 
 struct KernelStats {
@@ -187,41 +206,49 @@ struct Machine {
   const char* kernel = "";
   KernelStats* ks = nullptr;
   unsigned long long seed = 0, rng_state = 0;
-  unsigned rnd() {  // xorshift64*
+  EMU_NO_TSAN unsigned rnd() {  // xorshift64*
     rng_state ^= rng_state >> 12; rng_state ^= rng_state << 25; rng_state ^= rng_state >> 27;
     return (unsigned)((rng_state * 2685821657736338717ull) >> 33);
   }
   std::map<std::string, KernelStats> stats;
   int last_error = 0;  // what hipGetLastError() returns next
+  void* tsan_main = nullptr;
+  char tsan_block_sync = 0;            // happens-before carriers (addresses only)
+  char tsan_wave_sync[MAX_LANES / WAVE] = {};
   long allocations = 0, fail_allocation = -1;  // fault injection: the allocation with this ordinal fails
   long bad_launches = 0;
 };
 
-inline Machine& M() {
+EMU_NO_TSAN inline Machine& M() {
   static Machine m;
   return m;
 }
 
-[[noreturn]] inline void die(const char* what) {
+[[noreturn]] EMU_NO_TSAN inline void die(const char* what) {
   Machine& m = M();
   fprintf(stderr, "emu: %s  [kernel %s, block %u, work-item %d]\n", what, m.kernel, m.bidx.x, m.cur ? m.cur->index : -1);
   fflush(stderr);
   abort();
 }
 
-inline void switch_to_main(Lane* l, bool dying) {
+EMU_NO_TSAN inline void switch_to_main(Lane* l, bool dying) {
   Machine& m = M();
 #ifdef EMU_ASAN
   __sanitizer_start_switch_fiber(dying ? nullptr : &l->fake_stack, m.main_bottom, m.main_size);
 #endif
   (void)dying;
+#ifdef EMU_TSAN
+  // a work-item that has returned hands its history to the scheduler (the next workgroup starts after it);
+  // one that merely waits hands over nothing
+  __tsan_switch_to_fiber(m.tsan_main, dying ? 0 : __tsan_switch_to_fiber_no_sync);
+#endif
   emu_switch(&l->sp, m.main_sp);
 #ifdef EMU_ASAN
   __sanitizer_finish_switch_fiber(l->fake_stack, &m.main_bottom, &m.main_size);
 #endif
 }
 
-inline void trampoline() {
+EMU_NO_TSAN inline void trampoline() {
   Machine& m = M();
   Lane* l = m.cur;
 #ifdef EMU_ASAN
@@ -234,12 +261,15 @@ inline void trampoline() {
   abort();  // a finished fiber is never resumed
 }
 
-inline void resume(Lane* l) {
+EMU_NO_TSAN inline void resume(Lane* l) {
   Machine& m = M();
   m.cur = l;
 #ifdef EMU_ASAN
   void* fake = nullptr;
   __sanitizer_start_switch_fiber(&fake, m.stacks + (size_t)l->index * STACK_BYTES, STACK_BYTES);
+#endif
+#ifdef EMU_TSAN
+  __tsan_switch_to_fiber(l->tsan_fiber, __tsan_switch_to_fiber_no_sync);
 #endif
   emu_switch(&m.main_sp, l->sp);
 #ifdef EMU_ASAN
@@ -250,7 +280,7 @@ inline void resume(Lane* l) {
 
 // Record where the calling lane is: return addresses from the frame that called the emu entry point
 // out to (not including) the trampoline, then reversed.
-__attribute__((noinline)) inline void capture_position(Lane* l, void* frame) {
+EMU_NO_TSAN __attribute__((noinline)) inline void capture_position(Lane* l, void* frame) {
   uintptr_t tmp[MAX_CHAIN];
   int n = 0;
   void** fp = (void**)frame;
@@ -264,7 +294,7 @@ __attribute__((noinline)) inline void capture_position(Lane* l, void* frame) {
   for (int i = 0; i < n; ++i) l->chain[i] = tmp[n - 1 - i];
 }
 
-inline int compare_position(const Lane& a, const Lane& b) {
+EMU_NO_TSAN inline int compare_position(const Lane& a, const Lane& b) {
   const int n = std::min(a.nchain, b.nchain);
   for (int i = 0; i < n; ++i)
     if (a.chain[i] != b.chain[i]) return a.chain[i] < b.chain[i] ? -1 : 1;
@@ -272,29 +302,41 @@ inline int compare_position(const Lane& a, const Lane& b) {
 }
 
 // Block the calling lane in a wave-level operation; returns when the scheduler has filled `out`.
-__attribute__((noinline)) inline unsigned long long wave_op(Op op, unsigned long long in, int src, void* frame) {
+EMU_NO_TSAN __attribute__((noinline)) inline unsigned long long wave_op(Op op, unsigned long long in, int src, void* frame) {
   Machine& m = M();
   Lane* l = m.cur;
   if (!l) die("wave-level operation outside a kernel");
   l->op = op; l->in = in; l->src = src;
   capture_position(l, frame);
   l->st = AT_WAVE_OP;
+#ifdef EMU_TSAN
+  __tsan_release(&m.tsan_wave_sync[l->index / WAVE]);
+#endif
   switch_to_main(l, false);
+#ifdef EMU_TSAN
+  __tsan_acquire(&m.tsan_wave_sync[l->index / WAVE]);
+#endif
   return l->out;
 }
 
-__attribute__((noinline)) inline void barrier(void* frame) {
+EMU_NO_TSAN __attribute__((noinline)) inline void barrier(void* frame) {
   Machine& m = M();
   Lane* l = m.cur;
   if (!l) die("__syncthreads outside a kernel");
   capture_position(l, frame);
   l->st = AT_BARRIER;
+#ifdef EMU_TSAN
+  __tsan_release(&m.tsan_block_sync);
+#endif
   switch_to_main(l, false);
+#ifdef EMU_TSAN
+  __tsan_acquire(&m.tsan_block_sync);
+#endif
 }
 
 // The lanes of wave [lo, hi) that go next: the blocked lanes at the smallest program position.
 // Returns their state (AT_WAVE_OP or AT_BARRIER), or FINISHED if no lane of the wave is blocked.
-inline State wave_front(int lo, int hi, std::vector<int>& front) {
+EMU_NO_TSAN inline State wave_front(int lo, int hi, std::vector<int>& front) {
   Machine& m = M();
   front.clear();
   int lead = -1;
@@ -313,7 +355,7 @@ inline State wave_front(int lo, int hi, std::vector<int>& front) {
   return st;
 }
 
-inline void complete_wave_op(int lo, int hi, const std::vector<int>& front) {
+EMU_NO_TSAN inline void complete_wave_op(int lo, int hi, const std::vector<int>& front) {
   Machine& m = M();
   int live = 0;
   for (int i = lo; i < hi; ++i) live += m.lanes[i].st != FINISHED;
@@ -343,7 +385,7 @@ inline void complete_wave_op(int lo, int hi, const std::vector<int>& front) {
   for (int i : front) m.lanes[i].st = RUNNABLE;
 }
 
-inline void run_block() {
+EMU_NO_TSAN inline void run_block() {
   Machine& m = M();
   const int n = m.nlanes;
   const int nw = (n + WAVE - 1) / WAVE;
@@ -356,6 +398,9 @@ inline void run_block() {
     l.tid.z = i / (m.bdim.x * m.bdim.y);
     l.nchain = 0;
     l.fake_stack = nullptr;
+#ifdef EMU_TSAN
+    l.tsan_fiber = __tsan_create_fiber(0);  // inherits what the scheduler has seen so far, like a new thread
+#endif
     // first switch to the lane: six zeroed registers are popped, then `ret` enters trampoline()
     void** top = (void**)(m.stacks + (size_t)(i + 1) * STACK_BYTES);
     top[-1] = nullptr;
@@ -375,7 +420,12 @@ inline void run_block() {
       if (wstate[w] == 0) steppable.push_back(w);
       finished_waves += wstate[w] == 2;
     }
-    if (finished_waves == nw) return;
+    if (finished_waves == nw) {
+#ifdef EMU_TSAN
+      for (int i = 0; i < n; ++i) __tsan_destroy_fiber(m.lanes[i].tsan_fiber);
+#endif
+      return;
+    }
     if (steppable.empty()) {
       // every wave that still runs is at a barrier: they must all be at the same one
       int lead = -1;
@@ -410,7 +460,7 @@ inline void run_block() {
 }
 
 template <class... KArgs, class... Args>
-inline void launch(const char* name, void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t, hipStream_t, Args&&... args) {
+EMU_NO_TSAN inline void launch(const char* name, void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t, hipStream_t, Args&&... args) {
   Machine& m = M();
   std::lock_guard<std::mutex> lock(m.mu);
   std::tuple<std::decay_t<KArgs>...> held(static_cast<std::decay_t<KArgs>>(args)...);
@@ -431,6 +481,9 @@ inline void launch(const char* name, void (*kernel)(KArgs...), dim3 grid, dim3 b
     m.seed = (unsigned long long)env_int("EMU_SEED", 0);
     m.rng_state = m.seed * 0x9E3779B97F4A7C15ull + 1;
   }
+#ifdef EMU_TSAN
+  m.tsan_main = __tsan_get_current_fiber();
+#endif
   m.kernel = name;
   m.ks = &m.stats[name];
   ++m.ks->launches;
@@ -450,7 +503,7 @@ inline void launch(const char* name, void (*kernel)(KArgs...), dim3 grid, dim3 b
 }
 
 // Per-kernel totals since the process started, one line per kernel.
-inline void report(FILE* f) {
+EMU_NO_TSAN inline void report(FILE* f) {
   Machine& m = M();
   std::lock_guard<std::mutex> lock(m.mu);
   fprintf(f, "emu-bad-launches %ld\n", m.bad_launches);
@@ -530,7 +583,39 @@ __attribute__((noinline)) static void __syncthreads() { emu::barrier(__builtin_f
 static inline void __threadfence() {}
 static inline void __threadfence_block() {}
 
-// ---- atomics (one fiber runs at a time) -------------------------------------------------------
+// ---- atomics ------------------------------------------------------------------------------------
+// One fiber runs at a time, so plain read-modify-write is atomic here; the race-detection build uses real atomic
+// operations so that ThreadSanitizer knows these accesses are meant to be concurrent.
+#ifdef EMU_TSAN
+template <class T, class U>
+static inline T atomicAdd(T* p, U v) { return __atomic_fetch_add(p, (T)v, __ATOMIC_SEQ_CST); }
+template <class T, class U>
+static inline T atomicSub(T* p, U v) { return __atomic_fetch_sub(p, (T)v, __ATOMIC_SEQ_CST); }
+template <class T, class U>
+static inline T atomicOr(T* p, U v) { return __atomic_fetch_or(p, (T)v, __ATOMIC_SEQ_CST); }
+template <class T, class U>
+static inline T atomicAnd(T* p, U v) { return __atomic_fetch_and(p, (T)v, __ATOMIC_SEQ_CST); }
+template <class T, class U>
+static inline T atomicExch(T* p, U v) { return __atomic_exchange_n(p, (T)v, __ATOMIC_SEQ_CST); }
+template <class T, class U>
+static inline T atomicMin(T* p, U v) {
+  T old = __atomic_load_n(p, __ATOMIC_SEQ_CST);
+  while ((T)v < old && !__atomic_compare_exchange_n(p, &old, (T)v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {}
+  return old;
+}
+template <class T, class U>
+static inline T atomicMax(T* p, U v) {
+  T old = __atomic_load_n(p, __ATOMIC_SEQ_CST);
+  while (old < (T)v && !__atomic_compare_exchange_n(p, &old, (T)v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {}
+  return old;
+}
+template <class T, class U, class V>
+static inline T atomicCAS(T* p, U cmp, V v) {
+  T expected = (T)cmp;
+  __atomic_compare_exchange_n(p, &expected, (T)v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
+  return expected;
+}
+#else
 template <class T, class U>
 static inline T atomicAdd(T* p, U v) { T old = *p; *p = (T)(old + (T)v); return old; }
 template <class T, class U>
@@ -547,6 +632,7 @@ template <class T, class U>
 static inline T atomicExch(T* p, U v) { T old = *p; *p = (T)v; return old; }
 template <class T, class U, class V>
 static inline T atomicCAS(T* p, U cmp, V v) { T old = *p; if (old == (T)cmp) *p = (T)v; return old; }
+#endif
 
 // ---- memory, streams, events ------------------------------------------------------------------
 static inline const char* hipGetErrorString(hipError_t e) {

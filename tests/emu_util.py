@@ -22,7 +22,8 @@ def build(sanitize=True):
     subprocess.check_call(args)
 
 
-def run_emulated(data, cameras, params, workdir, want_hit=True, frames_per_scene=0, env=None, timeout=900):
+def run_emulated(data, cameras, params, workdir, want_hit=True, frames_per_scene=0, env=None, timeout=900, binary=None,
+                 with_stderr=False):
     """Render `cameras` (a list) of scene `data`; returns (frames, stats, stdout) where frames is a list of
     (rgba[H,W,4] u8, hit[H,W,spp] i32 or None, Counters) and stats maps kernel name -> dict of emulator totals."""
     workdir = str(workdir)
@@ -38,7 +39,7 @@ def run_emulated(data, cameras, params, workdir, want_hit=True, frames_per_scene
     e.setdefault("ASAN_OPTIONS", "detect_leaks=1:abort_on_error=0:detect_stack_use_after_return=0")
     e.setdefault("UBSAN_OPTIONS", "print_stacktrace=1")
     e.update(env or {})
-    r = subprocess.run([EMU_BIN, workdir], capture_output=True, text=True, timeout=timeout, env=e)
+    r = subprocess.run([binary or EMU_BIN, workdir], capture_output=True, text=True, timeout=timeout, env=e)
     if r.returncode != 0:
         raise AssertionError(f"emu_render exit {r.returncode}\n{r.stdout[-3000:]}\n{r.stderr[-6000:]}")
     W, H = params.width, params.height
@@ -58,4 +59,31 @@ def run_emulated(data, cameras, params, workdir, want_hit=True, frames_per_scene
         if line.startswith("emu-stats "):
             head, name = line.split(" kernel=", 1)  # the name is the launch expression as written, spaces included
             stats[name] = {k: int(v) for k, v in re.findall(r"(\w+)=(\d+)", head)}
-    return frames, stats, r.stdout
+    return (frames, stats, r.stdout, r.stderr) if with_stderr else (frames, stats, r.stdout)
+
+
+TSAN_BIN = os.path.join(EMU_DIR, "build_tsan", "emu_render")
+CSRC = os.path.join(HERE, "..", "raytracer_amd", "csrc")
+# Stores that several work-items may make at once ON PURPOSE: all of them store the same value (a flag that only
+# ever goes from 0 to nonzero), and it is read after the kernel has ended.
+BENIGN_RACY_STORES = ("cnt->overflow = 1", "cnt->bug = code", "ap->cnt->bug = ")
+
+
+def race_reports(stderr):
+    """ThreadSanitizer's data-race reports as lists of (file, line, source text) of the two accesses, without the
+    reports whose accesses are both one of the BENIGN_RACY_STORES."""
+    out = []
+    for rep in stderr.split("WARNING: ThreadSanitizer: data race")[1:]:
+        tops = re.findall(r"\n\s+#0 \S+.*? (/\S+?):(\d+)(?::\d+)? ", rep)[:2]
+        acc = []
+        for path, line in tops:
+            try:
+                with open(path) as f:
+                    text = f.read().split("\n")[int(line) - 1].strip()
+            except (OSError, IndexError):
+                text = "?"
+            acc.append((os.path.basename(path), int(line), text))
+        if acc and all(any(b in a[2] for b in BENIGN_RACY_STORES) for a in acc):
+            continue
+        out.append(acc or [("?", 0, rep[:400])])
+    return out

@@ -247,3 +247,42 @@ def test_emulated_degenerate_cameras(emu, oracle_mod, tmp_path, form):
         data.objects = np.concatenate([data.objects, scenes.sphere_object((0.5, 0.5, 1.0), 0.3, 0)])
     cams = [scenes.make_camera(*c) for c in DEGENERATE_CAMERAS.values()]
     run_case(emu, oracle_mod, tmp_path, data, cams, scenes.make_params(20, 16, 0.5))
+
+
+RACE_CASES = [
+    ("B", 2, (36, 30, 0.5), "tree", {}),
+    ("B", 2, (36, 30, 0.5), "scan", {"EMU_SEED": "4"}),
+    ("T", 2, (30, 24, 0.5), "tree", {"EMU_SEED": "2"}),
+    ("T", 2, (30, 24, 0.5), "scan", {}),
+    ("B", 2, (36, 30, 0.5), "tree", {"RTMI_CAND_CAPACITY": "64", "EMU_SEED": "6"}),      # overflowing candidate lists
+    ("B", 4, (30, 24, 0.5), "tree", {"RTMI_MAX_BATCH_SAMPLES": "2048", "EMU_SEED": "3"}),  # batches; tree packed by 10 workgroups
+]
+
+
+def test_emulated_kernels_have_no_data_races(emu, oracle_mod, tmp_path):
+    """The same kernels under ThreadSanitizer (make -C tests/emu tsan): every work-item is a sanitizer fiber, and
+    only wave-level operations, __syncthreads(), atomics and the end of a workgroup order them.  Two work-items of
+    a workgroup that touch one LDS or global location, one of them writing, with none of those in between, are
+    reported -- the kind of defect that shows on a GPU as a hang or a fault once in a while."""
+    subprocess.check_call(["make", "-s", "-C", emu.EMU_DIR, "tsan"])
+    r = subprocess.run([emu.EMU_DIR + "/build_tsan/emu_selftest", "race"], capture_output=True, text=True)
+    assert "ThreadSanitizer: data race" in r.stderr and "k_race" in r.stderr  # the detector detects
+    r = subprocess.run([emu.EMU_DIR + "/build_tsan/emu_selftest", "ok"], capture_output=True, text=True)
+    assert "selftest ok" in r.stdout and "ThreadSanitizer" not in r.stderr
+
+    def one(case):
+        k, (form, level, size, search, env) = case
+        data = scenes.mesh_scene(level=level, form=form, n_lights=3, bounding_sphere=oracle_mod.bounding_sphere)
+        cam = scenes.make_camera((0, 0, 4), (0, 0, -1), 10.0)
+        p = scenes.make_params(*size)
+        p.search = SEARCHES[search]
+        expected = [oracle_mod.render(data, cam, p, threads=2)] * 2
+        e = dict(env, TSAN_OPTIONS="halt_on_error=0 exitcode=0 report_signal_unsafe=0")
+        frames, stats, _, stderr = emu.run_emulated(data, [cam, cam], p, tmp_path / str(k), env=e, binary=emu.TSAN_BIN,
+                                                    with_stderr=True, timeout=1800)
+        check_frames(frames, stats, expected, p)
+        return emu.race_reports(stderr)
+
+    with ThreadPoolExecutor(6) as pool:
+        for case, reports in zip(RACE_CASES, pool.map(one, enumerate(RACE_CASES))):
+            assert not reports, (case, reports[:3])
