@@ -4,7 +4,8 @@
 // scene destruction is a reported error.
 //   * one scene object rendered at frame sizes that grow and shrink, with windows, tiles, all sample counts and a
 //     moving camera (work buffers regrown and reused, cached preparation invalidated), every frame compared with
-//     the oracle byte for byte;
+//     the oracle (oracle/rt_oracle.c, compiled into this program without OpenMP: its C code runs under the
+//     same sanitizers) byte for byte;
 //   * the begin/end protocol and its errors, destruction with a frame in flight;
 //   * every device allocation of scene creation and of a first frame made to fail in turn: the call must report
 //     out-of-memory (or succeed), leave nothing behind, and the next call must work.
