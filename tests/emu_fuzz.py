@@ -106,7 +106,7 @@ def random_case(seed, index):
     return data, cam, params
 
 
-def run_one(seed, index, oracle, keep_dir=None):
+def run_one(seed, index, oracle, keep_dir=None, tsan=False):
     from test_emulated_kernels import SEARCHES, check_frames
     data, cam, params = random_case(seed, index)
     expected = [oracle.render(data, cam, params, threads=1)] * 2
@@ -119,7 +119,14 @@ def run_one(seed, index, oracle, keep_dir=None):
         p = copy.copy(params)
         p.search = search
         with tempfile.TemporaryDirectory(dir=keep_dir) as d:
-            frames, stats, _ = emu_util.run_emulated(data, [cam, cam], p, d, env=env, timeout=600)
+            if tsan:
+                e = dict(env, TSAN_OPTIONS="halt_on_error=0 exitcode=0 report_signal_unsafe=0")
+                frames, stats, _, stderr = emu_util.run_emulated(data, [cam, cam], p, d, env=e, timeout=1800, binary=emu_util.TSAN_BIN,
+                                                                 with_stderr=True)
+                races = emu_util.race_reports(stderr)
+                assert not races, races[:3]
+            else:
+                frames, stats, _ = emu_util.run_emulated(data, [cam, cam], p, d, env=env, timeout=600)
             check_frames(frames, stats, expected, p)
 
 
@@ -129,16 +136,20 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--jobs", type=int, default=4)
     ap.add_argument("--only", type=int, default=None)
+    ap.add_argument("--tsan", action="store_true", help="run the ThreadSanitizer build and fail on any race report (make -C tests/emu tsan)")
     a = ap.parse_args()
     import oracle
     oracle.build()
     emu_util.build()
+    if a.tsan:
+        import subprocess
+        subprocess.check_call(["make", "-s", "-C", emu_util.EMU_DIR, "tsan"])
     todo = [a.only] if a.only is not None else list(range(a.cases))
     failed = []
 
     def job(i):
         try:
-            run_one(a.seed, i, oracle)
+            run_one(a.seed, i, oracle, tsan=a.tsan)
             return i, None
         except BaseException:  # noqa: BLE001
             return i, traceback.format_exc()

@@ -256,6 +256,8 @@ RACE_CASES = [
     ("T", 2, (30, 24, 0.5), "scan", {}),
     ("B", 2, (36, 30, 0.5), "tree", {"RTMI_CAND_CAPACITY": "64", "EMU_SEED": "6"}),      # overflowing candidate lists
     ("B", 4, (30, 24, 0.5), "tree", {"RTMI_MAX_BATCH_SAMPLES": "2048", "EMU_SEED": "3"}),  # batches; tree packed by 10 workgroups
+    ("B", 2, (24, 20, 0.5), "scan", {"CAMERA": "inside"}),  # triangles that subtend wide angles: flagged batches of the scan
+    ("T", 2, (24, 20, 0.5), "tree", {"CAMERA": "inside"}),
 ]
 
 
@@ -273,7 +275,9 @@ def test_emulated_kernels_have_no_data_races(emu, oracle_mod, tmp_path):
     def one(case):
         k, (form, level, size, search, env) = case
         data = scenes.mesh_scene(level=level, form=form, n_lights=3, bounding_sphere=oracle_mod.bounding_sphere)
-        cam = scenes.make_camera((0, 0, 4), (0, 0, -1), 10.0)
+        env = dict(env)
+        inside = env.pop("CAMERA", "") == "inside"
+        cam = scenes.make_camera((0.05, 0.02, 0.1), (0.1, 0.3, -1.0), 2.0) if inside else scenes.make_camera((0, 0, 4), (0, 0, -1), 10.0)
         p = scenes.make_params(*size)
         p.search = SEARCHES[search]
         expected = [oracle_mod.render(data, cam, p, threads=2)] * 2
@@ -283,6 +287,6 @@ def test_emulated_kernels_have_no_data_races(emu, oracle_mod, tmp_path):
         check_frames(frames, stats, expected, p)
         return emu.race_reports(stderr)
 
-    with ThreadPoolExecutor(6) as pool:
+    with ThreadPoolExecutor(8) as pool:
         for case, reports in zip(RACE_CASES, pool.map(one, enumerate(RACE_CASES))):
             assert not reports, (case, reports[:3])

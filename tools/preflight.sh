@@ -11,6 +11,7 @@ python tools/device_code_id.py
 make -s -C oracle
 python -m pytest tests/test_emulated_kernels.py -x -q
 python tests/emu_fuzz.py --cases "$CASES" --seed "$(date +%s)" --jobs 6
+python tests/emu_fuzz.py --tsan --cases "$((CASES / 5))" --seed "$(date +%s)" --jobs 6
 make -s -C tests/emu coverage
 rm -rf /tmp/rtmi_cov && mkdir -p /tmp/rtmi_cov
 EMU_RENDER_BIN=$PWD/tests/emu/build_cov/emu_render EMU_COVERAGE_FILE=/tmp/rtmi_cov/run \
