@@ -7,6 +7,7 @@
 //     the oracle (oracle/rt_oracle.c, compiled into this program without OpenMP: its C code runs under the
 //     same sanitizers) byte for byte;
 //   * the begin/end protocol and its errors, destruction with a frame in flight;
+//   * two host threads with a scene object each (this part is also run in the ThreadSanitizer build);
 //   * every device allocation of scene creation and of a first frame made to fail in turn: the call must report
 //     out-of-memory (or succeed), leave nothing behind, and the next call must work.
 #include <hip/hip_runtime.h>
@@ -14,6 +15,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "../../include/rtmi.h"
@@ -123,7 +125,8 @@ static int same_as_oracle(rtmi_scene* sc, const Scene& s, const rtmi_camera& cam
 
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-int main() {
+int main(int argc, char** argv) {
+  const bool only_threads = argc > 1 && !strcmp(argv[1], "threads");  // the part the race-detection build runs
   const double t_start = now_s();
   const Scene s = make_scene();
   const rtmi_scene_desc d = s.desc();
@@ -143,6 +146,7 @@ int main() {
       {44, 36, 0.5, {0, 0, 0, 0}, 0, 0, 1, 0, {0.2, 0.1, 0.3}},  // grows again; camera inside the geometry
   };
   for (const Shape& sh : shapes) {
+    if (only_threads) break;
     rtmi_params p = make_params(sh.w, sh.h, sh.sub);
     p.x0 = sh.win[0]; p.y0 = sh.win[1]; p.x1 = sh.win[2]; p.y1 = sh.win[3];
     p.tile_size = sh.tile; p.tile_rank = sh.rank; p.tile_world = sh.world;
@@ -152,7 +156,7 @@ int main() {
 
   printf("frame shapes: %.1f s\n", now_s() - t_start);
   // 2. protocol
-  {
+  if (!only_threads) {
     const rtmi_params p = make_params(20, 14, 0.5);
     const rtmi_camera cam = make_camera(0, 0, 4);
     uint8_t* frame = nullptr;
@@ -182,7 +186,7 @@ int main() {
 
   printf("protocol: %.1f s\n", now_s() - t_start);
   // 3. every allocation of creation + first frame fails once
-  {
+  if (!only_threads) {
     const rtmi_params p = make_params(7, 6, 1.0);  // small: the frame is rendered about a hundred times
     const rtmi_camera cam = make_camera(0, 0, 4);
     std::vector<uint8_t> frame((size_t)4 * 7 * 6);
@@ -210,6 +214,30 @@ int main() {
     printf("allocation failures injected: %d\n", failures);
   }
   printf("allocation failures: %.1f s\n", now_s() - t_start);
+  // 4. two host threads, each with a scene object of its own, rendering at the same time; a third reads error text
+  {
+    int failed[2] = {0, 0};
+    auto worker = [&](int who) {
+      rtmi_scene* t = nullptr;
+      if (rtmi_scene_create(&d, 0, &t) != RTMI_OK) { failed[who] = 1; return; }
+      for (int k = 0; k < 3 && !failed[who]; ++k) {
+        rtmi_params p = make_params(18 + 4 * who, 12 + 2 * k, who ? 0.5 : 1.0);
+        p.search = (who + k) & 1;
+        failed[who] = same_as_oracle(t, s, make_camera(0.3 * who, 0.2 * k, 4.0), p);
+        rtmi_params bad = p;
+        bad.width = 0;  // an error on this thread must not disturb the other's error text
+        std::vector<uint8_t> tmp(64);
+        if (rtmi_render(t, nullptr, &bad, tmp.data(), nullptr, nullptr) != RTMI_ERR_INVALID_ARGUMENT) failed[who] = 1;
+      }
+      rtmi_scene_destroy(t);
+    };
+    std::thread a(worker, 0), b(worker, 1);
+    a.join();
+    b.join();
+    REQUIRE(!failed[0] && !failed[1]);
+    printf("two host threads: %.1f s\n", now_s() - t_start);
+  }
+  if (sc) rtmi_scene_destroy(sc);
   printf("emu_api ok\n");
   return 0;
 }

@@ -469,7 +469,7 @@ EMU_NO_TSAN inline void launch(const char* name, void (*kernel)(KArgs...), dim3 
   if (n <= 0 || n > MAX_LANES || grid.x == 0 || grid.y == 0 || grid.z == 0) {
     // the runtime rejects an empty grid or workgroup: nothing runs and the launch reports an error
     fprintf(stderr, "emu: launch of %s with grid (%u,%u,%u) block (%u,%u,%u) rejected\n", name, grid.x, grid.y, grid.z, block.x, block.y, block.z);
-    m.last_error = 9;
+    __atomic_store_n(&m.last_error, 9, __ATOMIC_RELAXED);
     ++m.bad_launches;
     return;
   }
@@ -647,7 +647,8 @@ static inline const char* hipGetErrorString(hipError_t e) {
 }
 static inline hipError_t emu_alloc(void** p, size_t n) {
   if (!p) return hipErrorInvalidValue;
-  if (emu::M().allocations++ == emu::M().fail_allocation) return hipErrorOutOfMemory;
+  if (__atomic_fetch_add(&emu::M().allocations, 1L, __ATOMIC_RELAXED) == __atomic_load_n(&emu::M().fail_allocation, __ATOMIC_RELAXED))
+    return hipErrorOutOfMemory;  // (host threads may allocate at the same time)
   void* q = nullptr;
   if (posix_memalign(&q, 256, n ? n : 1) != 0) return hipErrorOutOfMemory;
   memset(q, emu::env_int("EMU_FILL", 0xA5), n ? n : 1);  // fresh device memory is not zero
@@ -675,12 +676,8 @@ static inline hipError_t hipMemcpyToSymbol(const void* symbol, const void* src, 
   memmove((char*)const_cast<void*>(symbol) + offset, src, n);
   return hipSuccess;
 }
-static inline hipError_t hipGetLastError() {
-  const int e = emu::M().last_error;
-  emu::M().last_error = 0;
-  return e;
-}
-static inline hipError_t hipPeekAtLastError() { return emu::M().last_error; }
+static inline hipError_t hipGetLastError() { return __atomic_exchange_n(&emu::M().last_error, 0, __ATOMIC_RELAXED); }
+static inline hipError_t hipPeekAtLastError() { return __atomic_load_n(&emu::M().last_error, __ATOMIC_RELAXED); }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int* n) { *n = emu::env_int("EMU_DEVICES", 1); return hipSuccess; }
 static inline hipError_t hipSetDevice(int d) { return d >= 0 && d < emu::env_int("EMU_DEVICES", 1) ? hipSuccess : hipErrorInvalidValue; }

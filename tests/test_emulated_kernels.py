@@ -272,6 +272,11 @@ def test_emulated_kernels_have_no_data_races(emu, oracle_mod, tmp_path):
     r = subprocess.run([emu.EMU_DIR + "/build_tsan/emu_selftest", "ok"], capture_output=True, text=True)
     assert "selftest ok" in r.stdout and "ThreadSanitizer" not in r.stderr
 
+    # the host side: two host threads, a scene object each (tests/emu/emu_api.cpp, last part)
+    r = subprocess.run([emu.EMU_DIR + "/build_tsan/emu_api", "threads"], capture_output=True, text=True, timeout=900,
+                       env={"TSAN_OPTIONS": "halt_on_error=0 exitcode=0"})
+    assert "emu_api ok" in r.stdout and not emu.race_reports(r.stderr), r.stdout[-500:] + r.stderr[-3000:]
+
     def one(case):
         k, (form, level, size, search, env) = case
         data = scenes.mesh_scene(level=level, form=form, n_lights=3, bounding_sphere=oracle_mod.bounding_sphere)
