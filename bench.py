@@ -67,7 +67,6 @@ def main():
                          "collectives run over gloo on host tensors (not a performance mode)")
     args = ap.parse_args()
 
-    import numpy as np
     import torch
     import torch.distributed as dist
 

@@ -21,7 +21,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 
 import emu_util  # noqa: E402
-from raytracer_amd import _abi, scenes  # noqa: E402
+from raytracer_amd import scenes  # noqa: E402
 
 GROUP_SIZES = (0, 1, 2, 7, 8, 9, 15, 16, 17, 63, 64, 65, 100, 260, 520)
 SUBDIVISIONS = (1.0, 1.0, 0.5, 0.5, 0.25, 0.4, 0.3, 0.7, 0.15)

@@ -3,8 +3,6 @@ RTMI_MAX_BATCH_SAMPLES set: renders frames that need several batches and compare
 import os
 import sys
 
-import numpy as np
-
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import oracle  # noqa: E402

@@ -7,9 +7,6 @@ Bar (stated once, used everywhere below):
     specular term is the only non-identical operation); the observed difference is 0 and the
     tests assert 0 so that any drift is noticed.
 """
-import ctypes as C
-import math
-
 import numpy as np
 import pytest
 

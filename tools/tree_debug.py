@@ -1,5 +1,4 @@
 """Counters and device times of one frame for both search strategies (debugging aid)."""
-import copy
 import os
 import sys
 
