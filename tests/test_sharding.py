@@ -88,3 +88,76 @@ def test_window_renders_equal_crops(oracle_mod):
     assert (phit[50:70, 40:90] == fhit[50:70, 40:90]).all()
     part[50:70, 40:90] = 0
     assert (part == 0).all()
+
+
+def _worker_abi(rank, world, port, q, lib_path, tile_size):
+    """The frame loop of bench.py (two scene objects per rank, frames alternating between two buffers, the gather of
+    frame i enqueued while frame i+1 renders) on CPU ranks: the renderer is the library's own C ABI, from the
+    CPU-emulated build of the kernels (tests/emu), loaded in place of librtmi.so IN THIS TEST PROCESS ONLY."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle
+        import raytracer_amd as rt
+        from raytracer_amd import scenes, sharding
+        rt.LIB_PATH = lib_path
+        W, H = 70, 52
+        data = scenes.mesh_scene(2, "B", 2, bounding_sphere=oracle.bounding_sphere) if rank == 0 else None
+        data = sharding.broadcast_scene(data, 0)
+        params = scenes.make_params(W, H, 0.5)
+        mine = sharding.tile_params(params, rank, world, tile_size=tile_size)
+        comp = sharding.TileComposer(W, H, rank, world, "cpu", tile_size=tile_size)
+        in_flight_scenes = [rt.Scene(data), rt.Scene(data)]
+        cams = [scenes.make_camera(**scenes.orbit_camera(f, 64)) for f in (0, 0, 3, 5, 5)]
+        in_flight, ok, composed = [], True, []
+
+        def retire():
+            sc, slot = in_flight.pop(0)
+            sc.render_end()
+            frame = comp.compose(slot)
+            if rank == 0:
+                composed.append(frame.numpy().copy())
+
+        for i, cam in enumerate(cams):
+            slot = i & 1
+            if len(in_flight) == 2:
+                retire()
+            comp.wait_slot(slot)
+            sc = in_flight_scenes[i % 2]
+            sc.render_begin(cam, mine, comp.frames[slot].data_ptr())
+            in_flight.append((sc, slot))
+        while in_flight:
+            retire()
+        for sc in in_flight_scenes:
+            sc.close()
+        if rank == 0:
+            for cam, frame in zip(cams, composed):
+                full, _, _ = oracle.render(data, cam, params)
+                ok = ok and bool((frame == full).all())
+            q.put((ok, len(composed)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,tile_size", [(2, 16), (3, 12)])
+def test_tile_sharded_frames_through_the_c_abi(world, tile_size):
+    """world ranks x the real host code and kernels (CPU-emulated build) x the real composer: every composed frame
+    equals the oracle's full frame.  Tile edge 16 is a multiple of the 8x8 sample blocks (block lists hold exactly
+    the owned pixels); 12 is not (per-pixel ownership test in the kernels)."""
+    import subprocess
+    emu_dir = os.path.join(ROOT, "tests", "emu")
+    subprocess.check_call(["make", "-s", "-C", emu_dir, "SAN=", "BUILD=build_ns", "build_ns/librtmi_emu.so"])
+    lib_path = os.path.join(emu_dir, "build_ns", "librtmi_emu.so")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29100 + (os.getpid() % 500) + 7 * world
+    procs = [ctx.Process(target=_worker_abi, args=(r, world, port, q, lib_path, tile_size)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    ok, n = q.get(timeout=5)
+    assert ok and n == 5
