@@ -92,5 +92,6 @@ public func raytraceWorld(camera: V3, cameraDirection: V3, focalLength: Double, 
     var counters = rtmi_counters()
     let rc = outputBitmap.withUnsafeMutableBufferPointer { rtmi_render(scene.handle, &cam, &p, $0.baseAddress, nil, &counters) }
     precondition(rc == RTMI_OK.rawValue, String(cString: rtmi_last_error()))
-    for _ in 0..<counters.samples { pixelDone?() }  // progress is reported after the frame, not per pixel
+    let spp = Int64(rtmi_samples_per_pixel(pixelSubdivision))
+    for _ in 0..<(counters.samples / spp) { pixelDone?() }  // once per rendered pixel (RayTracingFunctions.swift:112), after the frame
 }
