@@ -8,7 +8,7 @@ other.  Python floats are IEEE binary64 and math.sqrt is correctly rounded, like
 Pure-Python loops: small frames only.
 
 Reference files (under RayTraceUI/): RayTracingFunctions.swift, Renderables.swift, Utilities.swift,
-WorldCoordinateSequence.swift, ObjLoader.swift:52-59.
+WorldCoordinateSequence.swift, ObjLoader.swift, ViewController.swift:107-120 (the OBJ/MTL reader, at the end).
 """
 import math
 
@@ -441,3 +441,133 @@ def render(data, camera, params):
     amb = RGB(*[float(x) for x in params.ambient])
     return raytrace_world(V3(*camera.pos), V3(*camera.dir), float(camera.focal_length), params.width, params.height,
                           float(params.pixel_subdivision), amb, lights, objects)
+
+
+# ---- ObjLoader.swift, ViewController.swift:107-120 ----------------------------------------------
+class Trap(Exception):
+    """Where the Swift code would stop the program (a forced unwrap of nil, an index out of range)."""
+
+
+def swift_split(text, sep):
+    """String.split(separator:) with its default omittingEmptySubsequences: empty pieces vanish."""
+    return [p for p in text.split(sep) if p != ""]
+
+
+def swift_double(tok):
+    """Double(String): the whole token must be a number (no surrounding blanks, no underscores)."""
+    if tok != tok.strip() or "_" in tok or tok == "":
+        raise Trap(f"Double({tok!r}) is nil")
+    low = tok.lower().lstrip("+-")
+    if low in ("inf", "infinity", "nan"):
+        return float(tok)
+    try:
+        if low.startswith("0x"):
+            return float.fromhex(tok)
+        return float(tok)
+    except ValueError:
+        raise Trap(f"Double({tok!r}) is nil")
+
+
+def swift_int(tok):
+    body = tok[1:] if tok[:1] in "+-" else tok
+    if not body.isdigit() or not body.isascii():
+        raise Trap(f"Int({tok!r}) is nil")
+    return int(tok)
+
+
+def parse_numbers(line, conv):  # ObjLoader.swift:61-63
+    return [conv(t) for t in swift_split(line, " ")[1:]]
+
+
+def trim(line):
+    """trimToSubstring(in: .whitespacesAndNewlines) (:65-93) for the characters that occur in these files."""
+    return line.strip(" \t\r\n\x0b\x0c")
+
+
+def read_mtl_text(text):  # :95-158
+    ret = {}
+    lines = swift_split(text, "\n")
+    for i in range(len(lines)):
+        x = trim(lines[i])
+        if x.startswith("#") or x == "":
+            continue
+        if x.startswith("newmtl"):
+            toks = swift_split(x, " ")
+            if len(toks) < 2:
+                raise Trap("newmtl without a name")
+            name = toks[1]
+            f = {}
+            for j in range(i + 1, len(lines)):
+                ml = lines[j]
+                hit = False
+                for key, conv in (("Ns ", swift_double), ("d ", swift_double), ("illum ", swift_int)):
+                    if ml.startswith(key):
+                        vals = parse_numbers(ml, conv)
+                        if not vals:
+                            raise Trap("index 0 of an empty array")
+                        f[key] = vals[0]
+                        hit = True
+                        break
+                if hit:
+                    continue
+                for key in ("Kd ", "Ka ", "Ks "):
+                    if ml.startswith(key):
+                        vals = parse_numbers(ml, swift_double)
+                        if len(vals) != 3:
+                            raise Trap("RGB of other than three numbers is nil")
+                        f[key] = RGB(*vals)
+                        hit = True
+                        break
+                if hit:
+                    continue
+                if trim(ml) == "" or ml.startswith("newmtl"):
+                    break
+            for key in ("Ns ", "d ", "illum ", "Kd ", "Ka ", "Ks "):
+                if key not in f:
+                    raise Trap(f"material {name}: {key.strip()} is nil")
+            ret[name] = (f["Ns "], f["d "], f["illum "], f["Kd "], f["Ka "], f["Ks "])
+    return ret
+
+
+def read_obj_text(text):  # :160-201
+    vertices, faces = [], []
+    material = ""
+    for x in swift_split(text, "\n"):
+        if x.startswith("#"):
+            continue
+        if x.startswith("usemtl "):
+            toks = swift_split(x, " ")
+            material = toks[-1]
+            continue
+        if x.startswith("v "):
+            n = parse_numbers(x, swift_double)
+            if len(n) < 3:
+                raise Trap("vertex with fewer than three numbers")
+            vertices.append((n[0], n[1], n[2]))
+            continue
+        if x.startswith("vt "):
+            if len(parse_numbers(x, swift_double)) < 2:
+                raise Trap("vt with fewer than two numbers")
+            continue
+        if x.startswith("vn "):
+            if len(parse_numbers(x, swift_double)) < 3:
+                raise Trap("vn with fewer than three numbers")
+            continue
+        if x.startswith("f "):
+            n = parse_numbers(x, swift_int)
+            if len(n) < 3:
+                raise Trap("face with fewer than three indices")
+            faces.append(((n[0], n[1], n[2]), material))
+    return vertices, faces
+
+
+def create_triangle_list(vertices, faces):  # ViewController.swift:107-120
+    out = []
+    for (a, b, c), material in faces:
+        tri = []
+        for idx in (a - 1, b - 1, c - 1):
+            if idx < 0 or idx >= len(vertices):
+                raise Trap("vertex index out of range")
+            tri.append(vertices[idx])
+        out.append((tri, material))
+    return out
