@@ -258,7 +258,7 @@ def main():
                         "pow counted as 1) / launch time (HIP events on the library's stream).  An IEEE FP64 division costs "
                         "about 13 instructions on this ISA and a sqrt about 20, and the reference's arithmetic (3 divisions "
                         "per normalize) is kept operation for operation, so the kernel executes several instructions "
-                        "per counted operation; see DESIGN.md for the instruction-level accounting.",
+                        "per counted operation (about 2.6 on this kernel: 820 VALU instructions per 64 shaded hits, profiles/).",
             }
         out = {
             "metric": "Mrays/s + ray-tri tests/s (% FP32 peak), pig OBJ 4K 16spp, 1/2/4/8 GPU",
