@@ -118,7 +118,9 @@ typedef enum {
  * pixel_subdivision is WorldCoordinateSequence.pixelSubdivision (1, 0.5, 0.25 ...).
  * The pixel window and the cyclic tile selection restrict WHICH of those pixels are
  * rendered; pixel->world scaling always uses the full-frame constants.
- * Limits: 2 <= width, height <= 2^20 (larger: RTMI_ERR_UNSUPPORTED); at most 64 samples per pixel. */
+ * Limits: 2 <= width, height <= 2^20 and at most 2^26 8x8 pixel blocks per frame (larger:
+ * RTMI_ERR_UNSUPPORTED); at most 64 sub-samples per axis (4096 per pixel); a subdivision whose
+ * stride yields different sample counts at different pixels is refused (RTMI_ERR_UNSUPPORTED). */
 typedef struct {
   int32_t width;
   int32_t height;
@@ -168,7 +170,8 @@ const char* rtmi_status_string(int32_t status);
 /* Text of the last HIP failure on the calling thread ("" if none). */
 const char* rtmi_last_error(void);
 
-/* Number of gfx950 devices visible to the process, or a negative rtmi_status. */
+/* Number of HIP devices visible to the process (hipGetDeviceCount), or a negative rtmi_status.
+ * rtmi_scene_create refuses a device that is not gfx950 (RTMI_ERR_NO_DEVICE). */
 int32_t rtmi_device_count(void);
 
 /* Sphere(boundingObjects:) for a triangle list: centre = AABB midpoint, radius = half the
@@ -206,8 +209,13 @@ int32_t rtmi_render(rtmi_scene* scene, const rtmi_camera* camera, const rtmi_par
                     uint8_t* rgba_out, int32_t* hit_id_out, rtmi_counters* counters);
 
 /* Same, but rgba_dev / hit_id_dev are DEVICE pointers on the scene's device (e.g. a torch
- * tensor's data_ptr()).  All work is enqueued on an internal stream and the call returns
- * after that stream has drained. */
+ * tensor's data_ptr()).  All work is enqueued on the scene's own stream (created non-blocking:
+ * it is NOT ordered against the null stream or any stream of the caller) and the call returns
+ * after that stream has drained.
+ * Stream contract, for this call and for rtmi_render_begin: everything the caller has enqueued
+ * that writes or reads rgba_dev / hit_id_dev (a fill, a copy out of the previous frame) must have
+ * completed before the call, or be ordered before it with rtmi_scene_wait_event; the buffers must
+ * not be touched again until this call / rtmi_render_end has returned. */
 int32_t rtmi_render_device(rtmi_scene* scene, const rtmi_camera* camera,
                            const rtmi_params* params, void* rgba_dev, void* hit_id_dev,
                            rtmi_counters* counters);
@@ -221,6 +229,13 @@ int32_t rtmi_render_device(rtmi_scene* scene, const rtmi_camera* camera,
 int32_t rtmi_render_begin(rtmi_scene* scene, const rtmi_camera* camera, const rtmi_params* params,
                           void* rgba_dev, void* hit_id_dev);
 int32_t rtmi_render_end(rtmi_scene* scene, rtmi_counters* counters);
+
+/* Orders the scene's stream after work of the caller's: everything enqueued on the scene's stream
+ * after this call (the next rtmi_render_begin / rtmi_render_device) starts only when `hip_event`
+ * -- a hipEvent_t the caller has recorded on its own stream, on the scene's device -- has
+ * completed (hipStreamWaitEvent).  Does not block the host.  No counterpart in the reference,
+ * whose render is one synchronous call on one thread (ViewController.swift:154-180). */
+int32_t rtmi_scene_wait_event(rtmi_scene* scene, void* hip_event);
 
 /* Number of sub-samples per pixel for a subdivision value: the count of
  * stride(from: x, to: x+1, by: s) squared (WorldCoordinateSequence.swift:74-78). */

@@ -56,6 +56,8 @@ def lib():
         L.rtmi_render_begin.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Params), C.c_void_p, C.c_void_p]
         L.rtmi_render_end.restype = C.c_int32
         L.rtmi_render_end.argtypes = [C.c_void_p, C.POINTER(Counters)]
+        L.rtmi_scene_wait_event.restype = C.c_int32
+        L.rtmi_scene_wait_event.argtypes = [C.c_void_p, C.c_void_p]
         L.rtmi_obj_load.restype = C.c_int32
         L.rtmi_obj_load.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]
         L.rtmi_obj_free.restype = None
@@ -207,6 +209,11 @@ class Scene:
         rc = lib().rtmi_render_begin(self._h, C.byref(camera), C.byref(params), C.c_void_p(rgba_ptr),
                                      C.c_void_p(hit_ptr) if hit_ptr else None)
         _check(rc, "rtmi_render_begin")
+
+    def wait_event(self, hip_event):
+        """Order the scene's stream after `hip_event` (a raw hipEvent_t, e.g. torch.cuda.Event().cuda_event
+        once recorded): rtmi_scene_wait_event."""
+        _check(lib().rtmi_scene_wait_event(self._h, C.c_void_p(int(hip_event))), "rtmi_scene_wait_event")
 
     def render_end(self):
         """Wait for the frame in flight; returns its counters dict (rtmi_render_end)."""

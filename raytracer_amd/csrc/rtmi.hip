@@ -60,6 +60,23 @@ void rtmi_set_last_error(const std::string& msg) { g_last_error = msg; }  // use
     }                                                                                      \
   } while (0)
 
+// No C++ exception leaves the C ABI: a failed host allocation becomes RTMI_ERR_OUT_OF_MEMORY.
+template <class F>
+static int32_t guarded(F&& body) {
+  try {
+    return body();
+  } catch (const std::bad_alloc&) {
+    g_last_error = "out of host memory";
+    return RTMI_ERR_OUT_OF_MEMORY;
+  } catch (const std::exception& e) {
+    g_last_error = std::string("unexpected failure: ") + e.what();
+    return RTMI_ERR_HIP;
+  } catch (...) {
+    g_last_error = "unexpected failure";
+    return RTMI_ERR_HIP;
+  }
+}
+
 // Inline-asm constraint for "keep this value in a scalar register"; a build of the kernels for another
 // instruction set (the CPU build under tests/emu) names a register class of its own.
 #ifndef RTMI_SCALAR_REG
@@ -77,6 +94,29 @@ void rtmi_set_last_error(const std::string& msg) { g_last_error = msg; }  // use
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
+// Device memory a frame needs beyond the scene itself.  Per sample of a batch: outcome, queues, ray
+// direction, intersection parameter, colour, lowest list position; the candidate lists of the tree
+// search; the per-column and per-row sample tables; the list of 8x8 pixel blocks.
+struct WorkBufs {
+  size_t cap_samples = 0;
+  int* hit_id = nullptr;
+  int* tri_hit = nullptr;
+  int* q_child = nullptr;
+  int* q_shade = nullptr;
+  int* q_top = nullptr;
+  double* rgb = nullptr;
+  double* dirs = nullptr;
+  double* tval = nullptr;
+  int* best_pos = nullptr;   // tree search: per sample, lowest list position hit
+  int2* cand = nullptr;      // tree search: candidate pairs, cap_cand entries in NSLOT lists
+  size_t cap_cand = 0;
+  double* tabs = nullptr;    // utab then vtab (FP64), then their FP32 copies
+  size_t cap_tabs = 0;
+  int2* blocks = nullptr;
+  size_t cap_blocks = 0;
+  DevCounters* cnt = nullptr;  // work counters, queue and list fill levels
+};
+
 struct TriGroup {
   int object;          // owning object index (bounding sphere), or -1 for the top-level runs
   int n = 0;           // triangles in the group
@@ -121,35 +161,18 @@ struct rtmi_scene {
   TopTreeArgs top_args{};
   std::vector<TriGroup> groups;  // [0] = top-level runs (may be empty), then bounding objects
   SceneDev dev{};
-  // per-batch work buffers, grown on demand
-  size_t cap_samples = 0;
-  int* d_hit_id = nullptr;
-  int* d_tri_hit = nullptr;
-  int* d_q_child = nullptr;
-  int* d_q_shade = nullptr;
-  int* d_q_top = nullptr;
-  double* d_rgb = nullptr;
-  double* d_dirs = nullptr;
-  double* d_tval = nullptr;
-  int* d_best_pos = nullptr;   // tree search: per sample, lowest list position hit
-  int2* d_cand = nullptr;      // tree search: candidate pairs, cap_cand entries in NSLOT lists
-  size_t cap_cand = 0;
+  WorkBufs wb;  // per-batch work buffers, grown on demand
   std::vector<SearchArgs> h_sargs;   // one argument block per triangle group
   SearchArgs* d_sargs = nullptr;
-  double* d_tabs = nullptr;  // utab then vtab
-  size_t cap_tabs = 0;
   std::array<double, 18> tabs_key{};  // what the tables were computed for
   bool tabs_valid = false;
   std::vector<SearchArgs> sargs_uploaded;  // what d_sargs holds
   float4* d_genf = nullptr;                // k_gen pre-test operands, one per sphere-like object
   std::vector<float4> genf_uploaded;
   std::vector<rtmi_light> h_lights;
-  int2* d_blocks = nullptr;
-  size_t cap_blocks = 0;
   std::vector<int2> h_blocks;          // host copy of the block list last uploaded
   std::array<int, 9> blocks_key{};     // frame geometry + tile selection it was built for
   bool blocks_valid = false;
-  DevCounters* d_cnt = nullptr;
   int n_plain_shadeable = 0;  // spheres and lights in the object list (hits on them go through the shade queue)
   int exact_grid = 2048;  // workgroups of the grid-stride k_search_exact: eight per compute unit
   // one frame may be in flight between rtmi_render_begin and rtmi_render_end
@@ -294,16 +317,18 @@ extern "C" int32_t rtmi_bounding_sphere(const rtmi_triangle* tris, int64_t n, do
 extern "C" int32_t rtmi_tree_slot_order(const rtmi_triangle* tris, int64_t n, int32_t* slot_pos, int64_t capacity,
                                         int64_t* n_slots) {
   if ((!tris && n > 0) || n < 0 || n > 0x7ffffff0LL || !n_slots) return RTMI_ERR_INVALID_ARGUMENT;
-  std::vector<int> idx((size_t)n);
-  for (int64_t i = 0; i < n; ++i) idx[(size_t)i] = (int)i;
-  TreeHost th;
-  tree_build_host(tris, idx, &th);
-  *n_slots = (int64_t)th.slot_pos.size();
-  if (slot_pos) {
-    if (capacity < *n_slots) return RTMI_ERR_INVALID_ARGUMENT;
-    std::copy(th.slot_pos.begin(), th.slot_pos.end(), slot_pos);
-  }
-  return RTMI_OK;
+  return guarded([&]() -> int32_t {
+    std::vector<int> idx((size_t)n);
+    for (int64_t i = 0; i < n; ++i) idx[(size_t)i] = (int)i;
+    TreeHost th;
+    tree_build_host(tris, idx, &th);
+    *n_slots = (int64_t)th.slot_pos.size();
+    if (slot_pos) {
+      if (capacity < *n_slots) return RTMI_ERR_INVALID_ARGUMENT;
+      std::copy(th.slot_pos.begin(), th.slot_pos.end(), slot_pos);
+    }
+    return RTMI_OK;
+  });
 }
 
 extern "C" void rtmi_scene_destroy(rtmi_scene* sc) {
@@ -319,10 +344,10 @@ extern "C" void rtmi_scene_destroy(rtmi_scene* sc) {
   (void)hipFree(sc->d_objects); (void)hipFree(sc->d_lights); (void)hipFree(sc->d_materials);
   (void)hipFree(sc->d_tris); (void)hipFree(sc->d_planes); (void)hipFree(sc->d_tri_owner);
   (void)hipFree(sc->d_trec); (void)hipFree(sc->d_gst2);
-  (void)hipFree(sc->d_hit_id); (void)hipFree(sc->d_tri_hit); (void)hipFree(sc->d_q_child);
-  (void)hipFree(sc->d_q_shade); (void)hipFree(sc->d_q_top); (void)hipFree(sc->d_rgb);
-  (void)hipFree(sc->d_dirs); (void)hipFree(sc->d_tval); (void)hipFree(sc->d_best_pos); (void)hipFree(sc->d_cand); (void)hipFree(sc->d_tabs); (void)hipFree(sc->d_sargs); (void)hipFree(sc->d_genf);
-  (void)hipFree(sc->d_blocks); (void)hipFree(sc->d_cnt);
+  (void)hipFree(sc->wb.hit_id); (void)hipFree(sc->wb.tri_hit); (void)hipFree(sc->wb.q_child);
+  (void)hipFree(sc->wb.q_shade); (void)hipFree(sc->wb.q_top); (void)hipFree(sc->wb.rgb);
+  (void)hipFree(sc->wb.dirs); (void)hipFree(sc->wb.tval); (void)hipFree(sc->wb.best_pos); (void)hipFree(sc->wb.cand); (void)hipFree(sc->wb.tabs); (void)hipFree(sc->d_sargs); (void)hipFree(sc->d_genf);
+  (void)hipFree(sc->wb.blocks); (void)hipFree(sc->wb.cnt);
   if (sc->h_cnt) (void)hipHostFree(sc->h_cnt);
   for (auto& tr : sc->ev_pool) for (hipEvent_t e : tr) (void)hipEventDestroy(e);
   if (sc->ev_a) (void)hipEventDestroy(sc->ev_a);
@@ -471,7 +496,13 @@ static int32_t scene_create_impl(const rtmi_scene_desc* desc, int32_t device, rt
     for (int l = 0; l < TREE_MAX_LEVELS; ++l) sc->top_args.off[l] = td.rec_off[l];
   }
   for (auto& g : sc->groups) g.tree_host = TreeHost();  // host copies are not needed any more
-  HIP_TRY(hipMalloc(&sc->d_cnt, sizeof(DevCounters)));
+  HIP_TRY(hipMalloc(&sc->wb.cnt, sizeof(DevCounters)));
+  // one triple of timing events per triangle group: what a frame of one batch needs
+  for (size_t g = 0; g < sc->groups.size(); ++g) {
+    std::array<hipEvent_t, 3> t{};
+    for (hipEvent_t& e : t) HIP_TRY(hipEventCreate(&e));
+    sc->ev_pool.push_back(t);
+  }
   HIP_TRY(hipMalloc(&sc->d_genf, sizeof(float4) * std::max(1, n_sphere_like)));
   HIP_TRY(hipHostMalloc((void**)&sc->h_cnt, sizeof(DevCounters), hipHostMallocDefault));
   sc->h_sargs.resize(sc->groups.size());
@@ -501,7 +532,7 @@ extern "C" int32_t rtmi_scene_create(const rtmi_scene_desc* desc, int32_t device
   if (rc != RTMI_OK) return rc;
   rtmi_scene* sc = new (std::nothrow) rtmi_scene();
   if (!sc) return RTMI_ERR_OUT_OF_MEMORY;
-  rc = scene_create_impl(desc, device, sc);
+  rc = guarded([&] { return scene_create_impl(desc, device, sc); });
   if (rc != RTMI_OK) {
     rtmi_scene_destroy(sc);
     return rc;
@@ -511,42 +542,42 @@ extern "C" int32_t rtmi_scene_create(const rtmi_scene_desc* desc, int32_t device
 }
 
 static int32_t ensure_buffers(rtmi_scene* sc, size_t samples, size_t blocks) {
-  if (samples > sc->cap_samples) {
-    (void)hipFree(sc->d_hit_id); (void)hipFree(sc->d_tri_hit); (void)hipFree(sc->d_q_child);
-    (void)hipFree(sc->d_q_shade); (void)hipFree(sc->d_q_top); (void)hipFree(sc->d_rgb);
-    (void)hipFree(sc->d_dirs); (void)hipFree(sc->d_tval); (void)hipFree(sc->d_best_pos); (void)hipFree(sc->d_cand);
-    sc->d_hit_id = sc->d_tri_hit = sc->d_q_child = sc->d_q_shade = sc->d_q_top = sc->d_best_pos = nullptr;
-    sc->d_rgb = sc->d_dirs = sc->d_tval = nullptr;
-    sc->d_cand = nullptr;
-    sc->cap_samples = 0;
-    HIP_TRY(hipMalloc(&sc->d_hit_id, sizeof(int) * samples));
-    HIP_TRY(hipMalloc(&sc->d_tri_hit, sizeof(int) * samples));
-    HIP_TRY(hipMalloc(&sc->d_q_child, sizeof(int) * samples));
-    HIP_TRY(hipMalloc(&sc->d_q_shade, sizeof(int) * samples));
-    HIP_TRY(hipMalloc(&sc->d_q_top, sizeof(int) * samples));
-    HIP_TRY(hipMalloc(&sc->d_rgb, sizeof(double) * 3 * samples));
-    HIP_TRY(hipMalloc(&sc->d_dirs, sizeof(double) * 3 * samples));
-    HIP_TRY(hipMalloc(&sc->d_tval, sizeof(double) * samples));
-    HIP_TRY(hipMalloc(&sc->d_best_pos, sizeof(int) * samples));
+  if (samples > sc->wb.cap_samples) {
+    (void)hipFree(sc->wb.hit_id); (void)hipFree(sc->wb.tri_hit); (void)hipFree(sc->wb.q_child);
+    (void)hipFree(sc->wb.q_shade); (void)hipFree(sc->wb.q_top); (void)hipFree(sc->wb.rgb);
+    (void)hipFree(sc->wb.dirs); (void)hipFree(sc->wb.tval); (void)hipFree(sc->wb.best_pos); (void)hipFree(sc->wb.cand);
+    sc->wb.hit_id = sc->wb.tri_hit = sc->wb.q_child = sc->wb.q_shade = sc->wb.q_top = sc->wb.best_pos = nullptr;
+    sc->wb.rgb = sc->wb.dirs = sc->wb.tval = nullptr;
+    sc->wb.cand = nullptr;
+    sc->wb.cap_samples = 0;
+    HIP_TRY(hipMalloc(&sc->wb.hit_id, sizeof(int) * samples));
+    HIP_TRY(hipMalloc(&sc->wb.tri_hit, sizeof(int) * samples));
+    HIP_TRY(hipMalloc(&sc->wb.q_child, sizeof(int) * samples));
+    HIP_TRY(hipMalloc(&sc->wb.q_shade, sizeof(int) * samples));
+    HIP_TRY(hipMalloc(&sc->wb.q_top, sizeof(int) * samples));
+    HIP_TRY(hipMalloc(&sc->wb.rgb, sizeof(double) * 3 * samples));
+    HIP_TRY(hipMalloc(&sc->wb.dirs, sizeof(double) * 3 * samples));
+    HIP_TRY(hipMalloc(&sc->wb.tval, sizeof(double) * samples));
+    HIP_TRY(hipMalloc(&sc->wb.best_pos, sizeof(int) * samples));
     // A closed mesh that fills the frame yields about one candidate per sample; twice that, plus a
     // floor that keeps each of the NSLOT lists roomy when few waves share few lists (small frames).
-    sc->cap_cand = 2 * samples + (size_t)NSLOT * 16384;
+    sc->wb.cap_cand = 2 * samples + (size_t)NSLOT * 16384;
     // RTMI_CAND_CAPACITY (entries, for tests): a small value makes the lists overflow, which sends the frame
     // through the list scan instead (render_end)
     if (const char* e = getenv("RTMI_CAND_CAPACITY")) {
       const long long v = atoll(e);
-      if (v > 0) sc->cap_cand = (size_t)std::max<long long>(v, NSLOT);
+      if (v > 0) sc->wb.cap_cand = (size_t)std::max<long long>(v, NSLOT);
     }
-    HIP_TRY(hipMalloc(&sc->d_cand, sizeof(int2) * sc->cap_cand));
-    sc->cap_samples = samples;
+    HIP_TRY(hipMalloc(&sc->wb.cand, sizeof(int2) * sc->wb.cap_cand));
+    sc->wb.cap_samples = samples;
   }
-  if (blocks > sc->cap_blocks) {
-    (void)hipFree(sc->d_blocks);
-    sc->d_blocks = nullptr;
-    sc->cap_blocks = 0;
+  if (blocks > sc->wb.cap_blocks) {
+    (void)hipFree(sc->wb.blocks);
+    sc->wb.blocks = nullptr;
+    sc->wb.cap_blocks = 0;
     sc->blocks_valid = false;
-    HIP_TRY(hipMalloc(&sc->d_blocks, sizeof(int2) * blocks));
-    sc->cap_blocks = blocks;
+    HIP_TRY(hipMalloc(&sc->wb.blocks, sizeof(int2) * blocks));
+    sc->wb.cap_blocks = blocks;
   }
   return RTMI_OK;
 }
@@ -584,6 +615,7 @@ static int search_rays_per_lane() {
   return r;
 }
 constexpr int MAX_FRAME_EDGE = 1 << 20;          // widest and tallest frame accepted, in pixels
+constexpr int64_t MAX_FRAME_BLOCKS = 1ll << 26;  // 8x8 pixel blocks of a frame (the host keeps a list of them)
 constexpr size_t MAX_BATCH_SAMPLES = 1u << 28;  // 256 Mi samples per batch (about 100 B of work buffers per sample)
 
 // Frames with more samples than this are rendered in several batches of whole pixel blocks.
@@ -604,6 +636,10 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
   if (!sc || !cam || !p || !rgba_dev) return RTMI_ERR_INVALID_ARGUMENT;
   if (p->width < 2 || p->height < 2) return RTMI_ERR_INVALID_ARGUMENT;
   if (p->width > MAX_FRAME_EDGE || p->height > MAX_FRAME_EDGE) return RTMI_ERR_UNSUPPORTED;  // index arithmetic below is sized for this
+  if (((int64_t)p->width / BLK + 1) * ((int64_t)p->height / BLK + 1) > MAX_FRAME_BLOCKS) {
+    g_last_error = "frames of more than 2^26 pixel blocks (about 4.3 gigapixels) are not supported";
+    return RTMI_ERR_UNSUPPORTED;
+  }
   if (p->hit_policy != RTMI_HIT_LIST_ORDER) return RTMI_ERR_UNSUPPORTED;
   if (p->search != RTMI_SEARCH_CONE_TREE && p->search != RTMI_SEARCH_LIST_SCAN) return RTMI_ERR_INVALID_ARGUMENT;
   const bool use_tree = p->search == RTMI_SEARCH_CONE_TREE;
@@ -617,6 +653,23 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
   if (p->tile_size < 0 || p->tile_world < 0 || (p->tile_world > 1 && (p->tile_rank < 0 || p->tile_rank >= p->tile_world)))
     return RTMI_ERR_INVALID_ARGUMENT;
   if (p->tile_world > 1 && p->tile_size <= 0) return RTMI_ERR_INVALID_ARGUMENT;
+  // stride(from: x, to: x + 1, by: s) yields the values fma(k, s, x) < x + 1 (WorldCoordinateSequence.swift:74-75).
+  // The kernels assume the same count n1 for every pixel of the window; for a subdivision that puts
+  // some k*s within a rounding error of 1 the count can depend on x, and such a frame is refused.
+  {
+    const double s = p->pixel_subdivision;
+    auto uniform = [&](int lo, int hi) {
+      for (int c = lo; c < hi; ++c) {
+        const double x = (double)c;
+        if (!(fma((double)(n1 - 1), s, x) < x + 1.0) || fma((double)n1, s, x) < x + 1.0) return false;
+      }
+      return true;
+    };
+    if (!uniform(x0, x1) || !uniform(y0, y1)) {
+      g_last_error = "pixel_subdivision gives a sample count that varies from pixel to pixel";
+      return RTMI_ERR_UNSUPPORTED;
+    }
+  }
 
   if (sc->pending) {
     g_last_error = "a frame is already in flight on this scene; call rtmi_render_end first";
@@ -659,17 +712,17 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
   fc.inv_spp = 1.0f / (float)spp;
   {
     size_t need = (size_t)(p->width + p->height) * n1 * 3;
-    if (need > sc->cap_tabs) {
-      (void)hipFree(sc->d_tabs);
-      sc->d_tabs = nullptr;
-      sc->cap_tabs = 0;
-      HIP_TRY(hipMalloc(&sc->d_tabs, (sizeof(double) + sizeof(float)) * need));  // FP64 tables, then their FP32 copies
-      sc->cap_tabs = need;
+    if (need > sc->wb.cap_tabs) {
+      (void)hipFree(sc->wb.tabs);
+      sc->wb.tabs = nullptr;
+      sc->wb.cap_tabs = 0;
+      HIP_TRY(hipMalloc(&sc->wb.tabs, (sizeof(double) + sizeof(float)) * need));  // FP64 tables, then their FP32 copies
+      sc->wb.cap_tabs = need;
       sc->tabs_valid = false;
     }
-    fc.utab = sc->d_tabs;
-    fc.vtab = sc->d_tabs + (size_t)p->width * n1 * 3;
-    fc.utab_f = reinterpret_cast<const float*>(sc->d_tabs + sc->cap_tabs);
+    fc.utab = sc->wb.tabs;
+    fc.vtab = sc->wb.tabs + (size_t)p->width * n1 * 3;
+    fc.utab_f = reinterpret_cast<const float*>(sc->wb.tabs + sc->wb.cap_tabs);
     fc.vtab_f = fc.utab_f + (size_t)p->width * n1 * 3;
   }
 
@@ -717,11 +770,11 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
   const size_t max_batch_blocks = std::min(blocks_per_batch, std::max<size_t>(blocks.size(), 1));
   int32_t rc = ensure_buffers(sc, max_batch_blocks * samples_per_block, std::max<size_t>(blocks.size(), 1));
   if (rc) return rc;
-  sc->dev.n_samples = (int)std::min<size_t>(sc->cap_samples, 0x7fffffff);
+  sc->dev.n_samples = (int)std::min<size_t>(sc->wb.cap_samples, 0x7fffffff);
 
   hipStream_t st = sc->stream;
   HIP_TRY(hipEventRecord(sc->ev_a, st));
-  HIP_TRY(hipMemsetAsync(sc->d_cnt, 0, sizeof(DevCounters), st));
+  HIP_TRY(hipMemsetAsync(sc->wb.cnt, 0, sizeof(DevCounters), st));
 
   // FP32 pre-test of k_gen (scenes without top-level triangle runs: there every sample goes on to
   // the triangle search anyway).  d' = (ul - cam) + uComponent - vComponent in FP32 differs from
@@ -764,7 +817,7 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
   }
   if (!blocks_cached || !sc->blocks_valid) {
     if (!blocks.empty())
-      HIP_TRY(hipMemcpyAsync(sc->d_blocks, blocks.data(), sizeof(int2) * blocks.size(), hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemcpyAsync(sc->wb.blocks, blocks.data(), sizeof(int2) * blocks.size(), hipMemcpyHostToDevice, st));
     sc->blocks_key = blocks_key;
     sc->blocks_valid = true;
   }
@@ -778,8 +831,8 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
                                   (double)(uintptr_t)fc.utab, 0.0, 0.0};
     if (!sc->tabs_valid || memcmp(key.data(), sc->tabs_key.data(), sizeof(double) * key.size()) != 0) {
       int ntab = (p->width + p->height) * n1;
-      hipLaunchKernelGGL(k_frame_tables, dim3((ntab + 255) / 256), dim3(256), 0, st, fc, sc->d_tabs,
-                         sc->d_tabs + (size_t)p->width * n1 * 3, const_cast<float*>(fc.utab_f), const_cast<float*>(fc.vtab_f));
+      hipLaunchKernelGGL(k_frame_tables, dim3((ntab + 255) / 256), dim3(256), 0, st, fc, sc->wb.tabs,
+                         sc->wb.tabs + (size_t)p->width * n1 * 3, const_cast<float*>(fc.utab_f), const_cast<float*>(fc.vtab_f));
       sc->tabs_key = key;
       sc->tabs_valid = true;
     }
@@ -797,30 +850,30 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
   for (size_t gi = 0; gi < sc->groups.size(); ++gi) {
     const TriGroup& g = sc->groups[gi];
     SearchArgs& a = sc->h_sargs[gi];
-    a.queue = gi == 0 ? sc->d_q_top : sc->d_q_child;
-    a.nq_ptr = gi == 0 ? &sc->d_cnt->q_top : &sc->d_cnt->q_child;
+    a.queue = gi == 0 ? sc->wb.q_top : sc->wb.q_child;
+    a.nq_ptr = gi == 0 ? &sc->wb.cnt->q_top : &sc->wb.cnt->q_child;
     a.npacked_ptr = g.d_npacked;
     a.edge = g.d_edge;
     a.packed_tri = g.d_packed_tri;
-    a.dirs = sc->d_dirs;
-    a.tval = sc->d_tval;
-    a.hit_id = sc->d_hit_id;
-    a.tri_hit = sc->d_tri_hit;
-    a.q_shade = sc->d_q_shade;
-    a.cnt = sc->d_cnt;
+    a.dirs = sc->wb.dirs;
+    a.tval = sc->wb.tval;
+    a.hit_id = sc->wb.hit_id;
+    a.tri_hit = sc->wb.tri_hit;
+    a.q_shade = sc->wb.q_shade;
+    a.cnt = sc->wb.cnt;
     a.tris = sc->d_tris;
     a.planes = sc->d_planes;
     a.cam[0] = fc.cam[0]; a.cam[1] = fc.cam[1]; a.cam[2] = fc.cam[2];
     a.mode = gi == 0 ? 1 : 0;
     a.obj_filter = g.object;
     a.group = g.d_group;
-    a.best_pos = sc->d_best_pos;
-    a.cand = sc->d_cand;
+    a.best_pos = sc->wb.best_pos;
+    a.cand = sc->wb.cand;
     a.n_group = g.n;
-    a.n_samples = (int)std::min<size_t>(sc->cap_samples, 0x7fffffff);
+    a.n_samples = (int)std::min<size_t>(sc->wb.cap_samples, 0x7fffffff);
     a.n_tris = (int)sc->n_tris;
     a.n_records = (int)g.n_records;
-    a.cand_cap = (int)std::min<size_t>(sc->cap_cand, 0x7fffffff);
+    a.cand_cap = (int)std::min<size_t>(sc->wb.cap_cand, 0x7fffffff);
     a.tree = g.tree;
   }
   if (sc->sargs_uploaded.size() != sc->h_sargs.size() ||
@@ -852,11 +905,11 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
   for (size_t b0 = 0; b0 < blocks.size(); b0 += blocks_per_batch) {
     size_t nb = std::min(blocks_per_batch, blocks.size() - b0);
     int nsamples = (int)(nb * samples_per_block);
-    const int2* d_blk = sc->d_blocks + b0;
-    if (b0 > 0) HIP_TRY(hipMemsetAsync(&sc->d_cnt->q_child, 0, sizeof(int) * 3, st));  // the first batch starts from the cleared counters
+    const int2* d_blk = sc->wb.blocks + b0;
+    if (b0 > 0) HIP_TRY(hipMemsetAsync(&sc->wb.cnt->q_child, 0, sizeof(int) * 3, st));  // the first batch starts from the cleared counters
     int grid = (nsamples + 255) / 256;
-    hipLaunchKernelGGL(k_gen, dim3((nsamples + 256 * GEN_ITERS - 1) / (256 * GEN_ITERS)), dim3(256), 0, st, fc, sc->dev, d_blk, nsamples, sc->d_hit_id, sc->d_dirs, sc->d_q_child,
-                       sc->d_q_shade, sc->d_q_top, sc->d_cnt);
+    hipLaunchKernelGGL(k_gen, dim3((nsamples + 256 * GEN_ITERS - 1) / (256 * GEN_ITERS)), dim3(256), 0, st, fc, sc->dev, d_blk, nsamples, sc->wb.hit_id, sc->wb.dirs, sc->wb.q_child,
+                       sc->wb.q_shade, sc->wb.q_top, sc->wb.cnt);
     const int SR = search_rays_per_lane();
     const int search_grid = (nsamples + 256 * SR - 1) / (256 * SR);
     auto scan_kernel = SR == 8 ? k_search_primary<8> : (SR == 2 ? k_search_primary<2> : k_search_primary<4>);
@@ -880,7 +933,7 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
         else
           hipLaunchKernelGGL(has_top_runs ? k_shade_candidates<true> : k_shade_candidates<false>, dim3(sc->exact_grid), dim3(256),
                              0, st, shc, sc->dev, sc->top_args, (const f2*)sc->d_trec, (const float*)sc->d_gst2,
-                             (const int*)sc->groups[0].d_slot_pos, sc->d_sargs + gi, sc->d_rgb, par);
+                             (const int*)sc->groups[0].d_slot_pos, sc->d_sargs + gi, sc->wb.rgb, par);
       } else {
         hipLaunchKernelGGL(scan_kernel, dim3(search_grid), dim3(256), 0, st, sc->d_sargs + gi, (const f2*)g.d_cone);
         HIP_TRY(hipEventRecord(ev[1], st));
@@ -891,8 +944,8 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
     };
     if (sc->groups[0].n > 0) {
       if ((rc = search_group(0))) return rc;
-      hipLaunchKernelGGL(k_resolve_top, dim3(grid), dim3(256), 0, st, sc->dev, sc->d_q_top, &sc->d_cnt->q_top, sc->d_tri_hit,
-                         sc->d_tri_owner, sc->d_hit_id, sc->d_q_child, sc->d_q_shade, sc->d_cnt);
+      hipLaunchKernelGGL(k_resolve_top, dim3(grid), dim3(256), 0, st, sc->dev, sc->wb.q_top, &sc->wb.cnt->q_top, sc->wb.tri_hit,
+                         sc->d_tri_owner, sc->wb.hit_id, sc->wb.q_child, sc->wb.q_shade, sc->wb.cnt);
     }
     for (size_t gi = 1; gi < sc->groups.size(); ++gi)
       if ((rc = search_group(gi))) return rc;
@@ -901,18 +954,18 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
     if (!(use_tree && !has_top_runs && sc->n_plain_shadeable == 0)) {
       if (b0 == 0) HIP_TRY(hipEventRecord(sc->ev_c, st));  // timed for the first batch only (frames are one batch as a rule)
       hipLaunchKernelGGL(has_top_runs ? k_shade<true> : k_shade<false>, dim3(std::min(grid, 4 * sc->exact_grid)), dim3(256), 0, st, shc, sc->dev, sc->top_args, (const f2*)sc->d_trec,
-                         (const float*)sc->d_gst2, (const int*)sc->groups[0].d_slot_pos, sc->d_dirs, sc->d_tval, sc->d_q_shade, &sc->d_cnt->q_shade,
-                         sc->d_hit_id, sc->d_rgb, sc->d_cnt);
+                         (const float*)sc->d_gst2, (const int*)sc->groups[0].d_slot_pos, sc->wb.dirs, sc->wb.tval, sc->wb.q_shade, &sc->wb.cnt->q_shade,
+                         sc->wb.hit_id, sc->wb.rgb, sc->wb.cnt);
       if (b0 == 0) HIP_TRY(hipEventRecord(sc->ev_d, st));
       shade_queue_launched = true;
     }
     int npix = (int)(nb * BLK_PIX);
-    hipLaunchKernelGGL(k_resolve, dim3((npix + 255) / 256), dim3(256), 0, st, fc, d_blk, npix, sc->d_hit_id, sc->d_rgb,
-                       (const rtmi_object*)sc->d_objects, sc->dev.n_objects, sc->d_cnt, (unsigned char*)rgba_dev, (int*)hit_dev);
+    hipLaunchKernelGGL(k_resolve, dim3((npix + 255) / 256), dim3(256), 0, st, fc, d_blk, npix, sc->wb.hit_id, sc->wb.rgb,
+                       (const rtmi_object*)sc->d_objects, sc->dev.n_objects, sc->wb.cnt, (unsigned char*)rgba_dev, (int*)hit_dev);
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipEventRecord(sc->ev_b, st));
-  HIP_TRY(hipMemcpyAsync(sc->h_cnt, sc->d_cnt, sizeof(DevCounters), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(sc->h_cnt, sc->wb.cnt, sizeof(DevCounters), hipMemcpyDeviceToHost, st));
   sc->pend_launches = launches;
   sc->pend_live_samples = live_samples;
   sc->pend_shade_timed = shade_queue_launched;
@@ -931,10 +984,8 @@ static int32_t render_begin_impl(rtmi_scene* sc, const rtmi_camera* cam, const r
   return render_enqueue(sc, cam, p, rgba_dev, hit_dev);
 }
 
-// Wait for the frame enqueued by render_begin_impl and report its counters.
-static int32_t render_end_impl(rtmi_scene* sc, rtmi_counters* counters) {
-  if (!sc) return RTMI_ERR_INVALID_ARGUMENT;
-  std::lock_guard<std::mutex> lock(sc->mu);
+// Wait for the frame enqueued by render_enqueue and report its counters.  The caller holds sc->mu.
+static int32_t render_finish(rtmi_scene* sc, rtmi_counters* counters) {
   if (!sc->pending) {
     g_last_error = "no frame in flight on this scene";
     return RTMI_ERR_INVALID_ARGUMENT;
@@ -1004,6 +1055,12 @@ static int32_t render_end_impl(rtmi_scene* sc, rtmi_counters* counters) {
   return RTMI_OK;
 }
 
+static int32_t render_end_impl(rtmi_scene* sc, rtmi_counters* counters) {
+  if (!sc) return RTMI_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lock(sc->mu);
+  return render_finish(sc, counters);
+}
+
 static int32_t render_impl(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_params* p, void* rgba_dev,
                            void* hit_dev, rtmi_counters* counters) {
   int32_t rc = render_begin_impl(sc, cam, p, rgba_dev, hit_dev);
@@ -1013,18 +1070,31 @@ static int32_t render_impl(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_pa
 
 extern "C" int32_t rtmi_render_begin(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_params* p, void* rgba_dev,
                                      void* hit_dev) {
-  return render_begin_impl(sc, cam, p, rgba_dev, hit_dev);
+  return guarded([&] { return render_begin_impl(sc, cam, p, rgba_dev, hit_dev); });
 }
 
-extern "C" int32_t rtmi_render_end(rtmi_scene* sc, rtmi_counters* counters) { return render_end_impl(sc, counters); }
+extern "C" int32_t rtmi_render_end(rtmi_scene* sc, rtmi_counters* counters) {
+  return guarded([&] { return render_end_impl(sc, counters); });
+}
 
 extern "C" int32_t rtmi_render_device(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_params* p, void* rgba_dev,
                                       void* hit_dev, rtmi_counters* counters) {
-  return render_impl(sc, cam, p, rgba_dev, hit_dev, counters);
+  return guarded([&] { return render_impl(sc, cam, p, rgba_dev, hit_dev, counters); });
 }
 
-extern "C" int32_t rtmi_render(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_params* p, uint8_t* rgba_out,
-                               int32_t* hit_id_out, rtmi_counters* counters) {
+// Work enqueued on the scene's stream after this call starts only when `hip_event` has completed.
+extern "C" int32_t rtmi_scene_wait_event(rtmi_scene* sc, void* hip_event) {
+  return guarded([&]() -> int32_t {
+    if (!sc || !hip_event) return RTMI_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lock(sc->mu);
+    HIP_TRY(hipSetDevice(sc->device));
+    HIP_TRY(hipStreamWaitEvent(sc->stream, static_cast<hipEvent_t>(hip_event), 0));
+    return RTMI_OK;
+  });
+}
+
+static int32_t render_host_impl(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_params* p, uint8_t* rgba_out,
+                                int32_t* hit_id_out, rtmi_counters* counters) {
   if (!sc || !p || !rgba_out) return RTMI_ERR_INVALID_ARGUMENT;
   if (p->width < 2 || p->height < 2) return RTMI_ERR_INVALID_ARGUMENT;
   if (p->width > MAX_FRAME_EDGE || p->height > MAX_FRAME_EDGE) return RTMI_ERR_UNSUPPORTED;
@@ -1046,7 +1116,7 @@ extern "C" int32_t rtmi_render(rtmi_scene* sc, const rtmi_camera* cam, const rtm
     g_last_error = std::string("rtmi_render staging: ") + hipGetErrorString(e);
     rc = e == hipErrorOutOfMemory ? RTMI_ERR_OUT_OF_MEMORY : RTMI_ERR_HIP;
   }
-  if (rc == RTMI_OK) rc = render_impl(sc, cam, p, d_rgba, d_hit, counters);
+  if (rc == RTMI_OK) rc = guarded([&] { return render_impl(sc, cam, p, d_rgba, d_hit, counters); });
   if (rc == RTMI_OK) {
     e = hipMemcpy(rgba_out, d_rgba, nbytes, hipMemcpyDeviceToHost);
     if (e == hipSuccess && hit_id_out) e = hipMemcpy(hit_id_out, d_hit, sizeof(int) * nhit, hipMemcpyDeviceToHost);
@@ -1058,4 +1128,9 @@ extern "C" int32_t rtmi_render(rtmi_scene* sc, const rtmi_camera* cam, const rtm
   (void)hipFree(d_rgba);
   (void)hipFree(d_hit);
   return rc;
+}
+
+extern "C" int32_t rtmi_render(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_params* p, uint8_t* rgba_out,
+                               int32_t* hit_id_out, rtmi_counters* counters) {
+  return guarded([&] { return render_host_impl(sc, cam, p, rgba_out, hit_id_out, counters); });
 }

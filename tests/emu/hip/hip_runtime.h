@@ -81,7 +81,7 @@
 // an index past the end of a __shared__ array is reported.
 #define __shared__ static
 #define __constant__
-#define __align__(n) alignas(n)
+#define __align__(n) __attribute__((aligned(n)))
 #define HIP_SYMBOL(x) (&(x))  // a file-scope __device__ variable is an ordinary global here
 
 struct dim3 {
@@ -702,6 +702,7 @@ static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new emu_event_s{};
 static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned = 0) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
   *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
   return hipSuccess;

@@ -387,6 +387,7 @@ def test_begin_end_protocol_and_two_threads(oracle_mod, rt):
     # one frame in flight per scene: a second begin, or an end without a begin, is an error
     sc = rt.Scene(data_a)
     frame = torch.zeros((120, 160, 4), dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()  # the fill runs on torch's stream, the frame on the scene's: order them (rtmi.h, stream contract)
     with pytest.raises(rt.RtmiError):
         sc.render_end()
     sc.render_begin(cam_a, pa, frame.data_ptr())
@@ -518,3 +519,29 @@ def test_primary_rays_hit_point_lights(oracle_mod, rt):
     _, o_hit, _ = oracle_mod.render(data, cam, params)
     assert len({int(o_hit[j, i, 0]) for i, j in pixels} & {-2, -3, -5, -6}) >= 3
     assert_parity(oracle_mod, rt, data, cam, params)
+
+
+def test_wait_event_orders_the_scene_stream_after_the_callers_fill(oracle_mod, rt):
+    """rtmi_scene_wait_event: a fill enqueued on torch's stream, an event recorded behind it, and the frame
+    enqueued on the scene's stream without any host synchronisation in between; the frame must land on top
+    of the fill, never under it."""
+    import torch
+    data = scenes.mesh_scene(3, "B", 2, bounding_sphere=rt.bounding_sphere)
+    cam, p = scenes.make_camera(**scenes.MESH_CAMERA), scenes.make_params(320, 240, 0.5)
+    expect, _, _ = oracle_mod.render(data, cam, p, want_hit_ids=False, threads=8)
+    sc = rt.Scene(data)
+    frame = torch.zeros((240, 320, 4), dtype=torch.uint8, device="cuda:0")
+    big = torch.empty(1 << 28, dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    for _ in range(3):
+        big.fill_(1)       # keeps torch's stream busy, so that the fill below is still pending at render_begin
+        frame.fill_(0x33)
+        ev = torch.cuda.Event()
+        ev.record()
+        sc.wait_event(ev.cuda_event)
+        sc.render_begin(cam, p, frame.data_ptr())
+        sc.render_end()
+        got = frame.cpu().numpy()
+        assert (got[:239, :319] == expect[:239, :319]).all()
+        assert (got[239] == 0x33).all() and (got[:, 319] == 0x33).all()  # unrendered pixels keep the caller's bytes
+    sc.close()
