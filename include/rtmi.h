@@ -230,6 +230,23 @@ int32_t rtmi_render_begin(rtmi_scene* scene, const rtmi_camera* camera, const rt
                           void* rgba_dev, void* hit_id_dev);
 int32_t rtmi_render_end(rtmi_scene* scene, rtmi_counters* counters);
 
+/* rtmi_render_device for callers that cannot allocate device memory while they render: code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart in
+ * the reference.  The call allocates nothing on the device (no hipMalloc / hipFree, no allocating
+ * library routine): every work buffer of the frame -- per-sample outcomes, directions, colours,
+ * queues, candidate lists, sample tables, block list, counters -- is a slice of one array that the
+ * library holds in static device memory (9 MiB on each GPU it runs on, for the life of the process).
+ * Limits, beyond rtmi_render_device's: at most rtmi_noalloc_max_samples() = 65,536 samples, counted
+ * as (8x8 pixel blocks the window touches) x 64 x samples per pixel, and
+ * (width + height) x sub-samples per axis <= 16,384; a larger frame is refused with
+ * RTMI_ERR_UNSUPPORTED and rtmi_last_error() says which limit.  All calls on one GPU share that
+ * GPU's array: calls that overlap in time on one GPU (from several scenes or threads) race and
+ * must be serialised by the caller.  Results are identical to rtmi_render_device's. */
+int32_t rtmi_render_device_noalloc(rtmi_scene* scene, const rtmi_camera* camera,
+                                   const rtmi_params* params, void* rgba_dev, void* hit_id_dev,
+                                   rtmi_counters* counters);
+int64_t rtmi_noalloc_max_samples(void);
+
 /* Orders the scene's stream after work of the caller's: everything enqueued on the scene's stream
  * after this call (the next rtmi_render_begin / rtmi_render_device) starts only when `hip_event`
  * -- a hipEvent_t the caller has recorded on its own stream, on the scene's device -- has

@@ -56,6 +56,9 @@ def lib():
         L.rtmi_render_begin.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Params), C.c_void_p, C.c_void_p]
         L.rtmi_render_end.restype = C.c_int32
         L.rtmi_render_end.argtypes = [C.c_void_p, C.POINTER(Counters)]
+        L.rtmi_render_device_noalloc.restype = C.c_int32
+        L.rtmi_render_device_noalloc.argtypes = L.rtmi_render_device.argtypes
+        L.rtmi_noalloc_max_samples.restype = C.c_int64
         L.rtmi_scene_wait_event.restype = C.c_int32
         L.rtmi_scene_wait_event.argtypes = [C.c_void_p, C.c_void_p]
         L.rtmi_obj_load.restype = C.c_int32
@@ -202,6 +205,14 @@ class Scene:
         rc = lib().rtmi_render_device(self._h, C.byref(camera), C.byref(params), C.c_void_p(rgba_ptr),
                                       C.c_void_p(hit_ptr) if hit_ptr else None, C.byref(cnt))
         _check(rc, "rtmi_render_device")
+        return cnt.as_dict()
+
+    def render_device_noalloc(self, camera: Camera, params: Params, rgba_ptr: int, hit_ptr: int = 0):
+        """render_device without any device allocation, for small frames (rtmi_render_device_noalloc)."""
+        cnt = Counters()
+        rc = lib().rtmi_render_device_noalloc(self._h, C.byref(camera), C.byref(params), C.c_void_p(rgba_ptr),
+                                              C.c_void_p(hit_ptr) if hit_ptr else None, C.byref(cnt))
+        _check(rc, "rtmi_render_device_noalloc")
         return cnt.as_dict()
 
     def render_begin(self, camera: Camera, params: Params, rgba_ptr: int, hit_ptr: int = 0):

@@ -117,6 +117,76 @@ struct WorkBufs {
   DevCounters* cnt = nullptr;  // work counters, queue and list fill levels
 };
 
+// ---------------------------------------------------------------------------------------
+// static work buffers of rtmi_render_device_noalloc
+// ---------------------------------------------------------------------------------------
+// Callers that cannot allocate device memory (code under graph capture, serving loops, harnesses
+// that forbid it) render small frames with the work buffers below instead of buffers from
+// hipMalloc.  Every device the library runs on holds its own copy of the array, at its own
+// address, until the process ends; g_scratch_ptr[device] is that address (hipGetSymbolAddress with
+// the device current, at the first rtmi_scene_create on it).  Host code never uses the array's
+// name for anything else: the name is a host-side handle, not a device address.
+constexpr size_t NOALLOC_MAX_SAMPLES = 65536;                                  // samples of one frame (whole 8x8 blocks x spp)
+constexpr size_t NOALLOC_CAND = 2 * NOALLOC_MAX_SAMPLES + (size_t)NSLOT * 4096;  // candidate entries of the tree search
+constexpr size_t NOALLOC_TAB_ENTRIES = 16384;                                  // (width + height) x sub-samples per axis
+constexpr size_t NOALLOC_BLOCKS = NOALLOC_MAX_SAMPLES / BLK_PIX;
+constexpr size_t SCRATCH_BYTES = 9u << 20;
+constexpr int MAX_DEVICES = 64;
+
+static __device__ __align__(256) unsigned char scratch[SCRATCH_BYTES];
+
+static std::mutex g_scratch_mu;
+static unsigned char* g_scratch_ptr[MAX_DEVICES];
+
+constexpr size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+constexpr size_t scratch_bytes_needed() {
+  return 6 * align256(sizeof(int) * NOALLOC_MAX_SAMPLES) + 2 * align256(sizeof(double) * 3 * NOALLOC_MAX_SAMPLES) +
+         align256(sizeof(double) * NOALLOC_MAX_SAMPLES) + align256(sizeof(int2) * NOALLOC_CAND) +
+         align256((sizeof(double) + sizeof(float)) * 3 * NOALLOC_TAB_ENTRIES) + align256(sizeof(int2) * NOALLOC_BLOCKS) +
+         align256(sizeof(DevCounters));
+}
+static_assert(scratch_bytes_needed() <= SCRATCH_BYTES, "the static array is too small for its slices");
+
+// The slices of a device's static array, in the shape the render path expects.
+static WorkBufs carve_scratch(unsigned char* base) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    void* p = base + off;
+    off += align256(bytes);
+    return p;
+  };
+  WorkBufs w;
+  w.cap_samples = NOALLOC_MAX_SAMPLES;
+  w.hit_id = (int*)take(sizeof(int) * NOALLOC_MAX_SAMPLES);
+  w.tri_hit = (int*)take(sizeof(int) * NOALLOC_MAX_SAMPLES);
+  w.q_child = (int*)take(sizeof(int) * NOALLOC_MAX_SAMPLES);
+  w.q_shade = (int*)take(sizeof(int) * NOALLOC_MAX_SAMPLES);
+  w.q_top = (int*)take(sizeof(int) * NOALLOC_MAX_SAMPLES);
+  w.best_pos = (int*)take(sizeof(int) * NOALLOC_MAX_SAMPLES);
+  w.rgb = (double*)take(sizeof(double) * 3 * NOALLOC_MAX_SAMPLES);
+  w.dirs = (double*)take(sizeof(double) * 3 * NOALLOC_MAX_SAMPLES);
+  w.tval = (double*)take(sizeof(double) * NOALLOC_MAX_SAMPLES);
+  w.cand = (int2*)take(sizeof(int2) * NOALLOC_CAND);
+  w.cap_cand = NOALLOC_CAND;
+  w.tabs = (double*)take((sizeof(double) + sizeof(float)) * 3 * NOALLOC_TAB_ENTRIES);
+  w.cap_tabs = 3 * NOALLOC_TAB_ENTRIES;
+  w.blocks = (int2*)take(sizeof(int2) * NOALLOC_BLOCKS);
+  w.cap_blocks = NOALLOC_BLOCKS;
+  w.cnt = (DevCounters*)take(sizeof(DevCounters));
+  return w;
+}
+
+// Address of `scratch` on `device`, which must be the current device.
+static int32_t scratch_init(int device) {
+  if (device < 0 || device >= MAX_DEVICES) return RTMI_OK;  // rtmi_render_device_noalloc is refused there
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (g_scratch_ptr[device]) return RTMI_OK;
+  void* p = nullptr;
+  HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+  g_scratch_ptr[device] = static_cast<unsigned char*>(p);
+  return RTMI_OK;
+}
+
 struct TriGroup {
   int object;          // owning object index (bounding sphere), or -1 for the top-level runs
   int n = 0;           // triangles in the group
@@ -161,7 +231,10 @@ struct rtmi_scene {
   TopTreeArgs top_args{};
   std::vector<TriGroup> groups;  // [0] = top-level runs (may be empty), then bounding objects
   SceneDev dev{};
-  WorkBufs wb;  // per-batch work buffers, grown on demand
+  // per-batch work buffers: the scene's own (grown on demand), or for the duration of one
+  // rtmi_render_device_noalloc call slices of the library's static device array
+  WorkBufs wb;
+  bool no_alloc = false;  // the frame being enqueued must fit the buffers as they are
   std::vector<SearchArgs> h_sargs;   // one argument block per triangle group
   SearchArgs* d_sargs = nullptr;
   std::array<double, 18> tabs_key{};  // what the tables were computed for
@@ -380,6 +453,10 @@ static int32_t scene_create_impl(const rtmi_scene_desc* desc, int32_t device, rt
     sc->exact_grid = ((std::max(1, prop.multiProcessorCount) * per_cu + NSLOT - 1) / NSLOT) * NSLOT;
   }
   HIP_TRY(hipSetDevice(device));
+  {
+    int32_t rc0 = scratch_init(device);
+    if (rc0 != RTMI_OK) return rc0;
+  }
   HIP_TRY(hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreate(&sc->ev_a));
   HIP_TRY(hipEventCreate(&sc->ev_b));
@@ -542,6 +619,12 @@ extern "C" int32_t rtmi_scene_create(const rtmi_scene_desc* desc, int32_t device
 }
 
 static int32_t ensure_buffers(rtmi_scene* sc, size_t samples, size_t blocks) {
+  if (sc->no_alloc && (samples > sc->wb.cap_samples || blocks > sc->wb.cap_blocks)) {
+    g_last_error = "rtmi_render_device_noalloc: the frame needs " + std::to_string(samples) + " samples of work buffers in " +
+                   std::to_string(blocks) + " pixel blocks; the static array holds " + std::to_string(sc->wb.cap_samples) +
+                   " samples in " + std::to_string(sc->wb.cap_blocks) + " blocks";
+    return RTMI_ERR_UNSUPPORTED;
+  }
   if (samples > sc->wb.cap_samples) {
     (void)hipFree(sc->wb.hit_id); (void)hipFree(sc->wb.tri_hit); (void)hipFree(sc->wb.q_child);
     (void)hipFree(sc->wb.q_shade); (void)hipFree(sc->wb.q_top); (void)hipFree(sc->wb.rgb);
@@ -712,6 +795,11 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
   fc.inv_spp = 1.0f / (float)spp;
   {
     size_t need = (size_t)(p->width + p->height) * n1 * 3;
+    if (need > sc->wb.cap_tabs && sc->no_alloc) {
+      g_last_error = "rtmi_render_device_noalloc: (width + height) x sub-samples per axis = " + std::to_string(need / 3) +
+                     " table entries; the static array holds " + std::to_string(sc->wb.cap_tabs / 3);
+      return RTMI_ERR_UNSUPPORTED;
+    }
     if (need > sc->wb.cap_tabs) {
       (void)hipFree(sc->wb.tabs);
       sc->wb.tabs = nullptr;
@@ -892,6 +980,10 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
   sc->ev_used = 0;
   auto next_events = [&](hipEvent_t** ev) -> int32_t {
     if (sc->ev_used == sc->ev_pool.size()) {
+      if (sc->no_alloc) {  // cannot happen: one triple per triangle group exists since the scene was created
+        g_last_error = "rtmi_render_device_noalloc: out of timing events";
+        return RTMI_ERR_UNSUPPORTED;
+      }
       std::array<hipEvent_t, 3> t{};
       for (hipEvent_t& e : t) HIP_TRY(hipEventCreate(&e));
       sc->ev_pool.push_back(t);
@@ -1068,6 +1160,48 @@ static int32_t render_impl(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_pa
   return render_end_impl(sc, counters);
 }
 
+// Everything the camera- and geometry-keyed caches say about the work buffers' contents is forgotten
+// (the buffers are about to change hands).
+static void forget_buffer_caches(rtmi_scene* sc) {
+  sc->tabs_valid = false;
+  sc->blocks_valid = false;
+  sc->sargs_uploaded.clear();
+}
+
+// rtmi_render_device with the device's static array in place of the scene's own work buffers.
+static int32_t render_noalloc_impl(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_params* p, void* rgba_dev,
+                                   void* hit_dev, rtmi_counters* counters) {
+  if (!sc) return RTMI_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lock(sc->mu);
+  if (sc->pending) {
+    g_last_error = "a frame is already in flight on this scene; call rtmi_render_end first";
+    return RTMI_ERR_INVALID_ARGUMENT;
+  }
+  unsigned char* base = nullptr;
+  if (sc->device >= 0 && sc->device < MAX_DEVICES) {
+    std::lock_guard<std::mutex> slock(g_scratch_mu);
+    base = g_scratch_ptr[sc->device];
+  }
+  if (!base) {
+    g_last_error = "rtmi_render_device_noalloc: no static work array on device " + std::to_string(sc->device);
+    return RTMI_ERR_UNSUPPORTED;
+  }
+  WorkBufs own = sc->wb;
+  sc->wb = carve_scratch(base);
+  sc->no_alloc = true;
+  forget_buffer_caches(sc);
+  int32_t rc = render_enqueue(sc, cam, p, rgba_dev, hit_dev);
+  if (rc == RTMI_OK) rc = render_finish(sc, counters);  // a candidate-list overflow renders again, within the same limits
+  if (rc != RTMI_OK) {  // whatever was enqueued before the failure is drained before the buffers change back
+    (void)hipStreamSynchronize(sc->stream);
+    sc->pending = false;
+  }
+  sc->no_alloc = false;
+  sc->wb = own;
+  forget_buffer_caches(sc);
+  return rc;
+}
+
 extern "C" int32_t rtmi_render_begin(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_params* p, void* rgba_dev,
                                      void* hit_dev) {
   return guarded([&] { return render_begin_impl(sc, cam, p, rgba_dev, hit_dev); });
@@ -1081,6 +1215,13 @@ extern "C" int32_t rtmi_render_device(rtmi_scene* sc, const rtmi_camera* cam, co
                                       void* hit_dev, rtmi_counters* counters) {
   return guarded([&] { return render_impl(sc, cam, p, rgba_dev, hit_dev, counters); });
 }
+
+extern "C" int32_t rtmi_render_device_noalloc(rtmi_scene* sc, const rtmi_camera* cam, const rtmi_params* p,
+                                              void* rgba_dev, void* hit_dev, rtmi_counters* counters) {
+  return guarded([&] { return render_noalloc_impl(sc, cam, p, rgba_dev, hit_dev, counters); });
+}
+
+extern "C" int64_t rtmi_noalloc_max_samples(void) { return (int64_t)NOALLOC_MAX_SAMPLES; }
 
 // Work enqueued on the scene's stream after this call starts only when `hip_event` has completed.
 extern "C" int32_t rtmi_scene_wait_event(rtmi_scene* sc, void* hip_event) {

@@ -2,7 +2,8 @@
 // TEST INFRASTRUCTURE, used by tests/test_emulated_kernels.py.
 //
 //   emu_render <dir>
-// reads  <dir>/job.bin        int32 n_frames, int32 want_hit_ids, int32 frames_per_scene, int32 reserved,
+// reads  <dir>/job.bin        int32 n_frames, int32 want_hit_ids, int32 frames_per_scene, int32 entry (0: rtmi_render,
+//                             1: rtmi_render_device_noalloc; "device" memory is host memory in this build),
 //                             rtmi_params, then n_frames rtmi_camera
 //        <dir>/lights.bin, materials.bin, objects.bin, triangles.bin   the arrays of rtmi_scene_desc
 // writes <dir>/rgba_<k>.bin, hit_<k>.bin, counters_<k>.bin for frame k, and one "frame k status s"
@@ -43,7 +44,7 @@ int main(int argc, char** argv) {
   if (job.size() < 16 + sizeof(rtmi_params)) { fprintf(stderr, "short job.bin\n"); return 2; }
   int32_t head[4];
   memcpy(head, job.data(), 16);
-  const int n_frames = head[0], want_hit = head[1], per_scene = head[2];
+  const int n_frames = head[0], want_hit = head[1], per_scene = head[2], entry = head[3];
   rtmi_params params;
   memcpy(&params, job.data() + 16, sizeof params);
   if (job.size() != 16 + sizeof(rtmi_params) + (size_t)n_frames * sizeof(rtmi_camera)) { fprintf(stderr, "job.bin size mismatch\n"); return 2; }
@@ -75,7 +76,8 @@ int main(int argc, char** argv) {
     std::vector<uint8_t> rgba(npx * 4, 0x5A);
     std::vector<int32_t> hit(want_hit ? npx * (size_t)std::max(spp, 1) : 0, -77);
     rtmi_counters cnt{};
-    int rc = rtmi_render(scene, &cams[k], &params, rgba.data(), want_hit ? hit.data() : nullptr, &cnt);
+    int rc = entry == 1 ? rtmi_render_device_noalloc(scene, &cams[k], &params, rgba.data(), want_hit ? hit.data() : nullptr, &cnt)
+                        : rtmi_render(scene, &cams[k], &params, rgba.data(), want_hit ? hit.data() : nullptr, &cnt);
     printf("frame %d status %d %s\n", k, rc, rc ? rtmi_last_error() : "");
     if (rc) rc_all = 1;
     const std::string tag = std::to_string(k);

@@ -23,7 +23,7 @@ def build(sanitize=True):
 
 
 def run_emulated(data, cameras, params, workdir, want_hit=True, frames_per_scene=0, env=None, timeout=900, binary=None,
-                 with_stderr=False):
+                 with_stderr=False, noalloc=False):
     """Render `cameras` (a list) of scene `data`; returns (frames, stats, stdout) where frames is a list of
     (rgba[H,W,4] u8, hit[H,W,spp] i32 or None, Counters) and stats maps kernel name -> dict of emulator totals."""
     workdir = str(workdir)
@@ -31,7 +31,7 @@ def run_emulated(data, cameras, params, workdir, want_hit=True, frames_per_scene
     for k, a in data.to_arrays().items():
         np.ascontiguousarray(a).tofile(os.path.join(workdir, k + ".bin"))
     with open(os.path.join(workdir, "job.bin"), "wb") as f:
-        f.write(struct.pack("<4i", len(cameras), int(want_hit), int(frames_per_scene), 0))
+        f.write(struct.pack("<4i", len(cameras), int(want_hit), int(frames_per_scene), int(noalloc)))
         f.write(bytes(params))
         for c in cameras:
             f.write(bytes(c))
