@@ -58,6 +58,9 @@ def main():
     ap.add_argument("--no-scan-leg", action="store_true",
                     help="skip the extra list-scan frames that measure BASELINE's tests/s figure (1 GPU only)")
     ap.add_argument("--orbit", action="store_true", help="config 5: move the camera every step")
+    ap.add_argument("--ray-stats", action="store_true",
+                    help="keep the reference's ray statistics in the timed frames (every ray the reference would trace is "
+                         "counted, which costs the tracing of rays that cannot change a pixel)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--verify", action="store_true",
@@ -116,7 +119,10 @@ def main():
     scene = rt.Scene(data, device=local_rank)
     from raytracer_amd import _abi
     search = _abi.RTMI_SEARCH_CONE_TREE if args.search == "tree" else _abi.RTMI_SEARCH_LIST_SCAN
-    params = scenes.make_params(W, H, sub, search=search)
+    # timed frames ask for pixels only (RTMI_FLAG_NO_RAY_STATISTICS): rays whose outcome cannot change a pixel are then
+    # neither traced nor counted; --ray-stats keeps the reference's full ray statistics inside the timed region
+    flags = 0 if args.ray_stats else _abi.RTMI_FLAG_NO_RAY_STATISTICS
+    params = scenes.make_params(W, H, sub, search=search, flags=flags)
     my_params = sharding.tile_params(params, rank, world) if world > 1 else params
     composer = sharding.TileComposer(W, H, rank, world, comm_dev)
     staging = [torch.zeros((H, W, 4), dtype=torch.uint8, device=dev) for _ in range(2)] if args.rehearse_gloo else None

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RTMI_ABI_VERSION 2
+#define RTMI_ABI_VERSION 3
 
 typedef enum {
   RTMI_OK = 0,
@@ -132,7 +132,17 @@ typedef struct {
   int32_t tile_rank;      /* render tiles whose id % tile_world == tile_rank */
   int32_t tile_world;     /* <= 1 = every tile */
   int32_t search;         /* rtmi_search */
+  int32_t flags;          /* RTMI_FLAG_* bits; 0 = none */
 } rtmi_params;
+
+/* The caller wants the pixels (and hit ids), not the reference's ray statistics: secondary rays whose outcome
+ * cannot change a pixel need then be neither traced nor counted, and rays_reflection / rays_shadow /
+ * shadow_rays_elided of rtmi_counters count only the rays that were traced.  Today this makes a difference for
+ * scenes whose top-level list holds nothing but bounding spheres without a material -- what loadObjFile
+ * builds (ViewController.swift:101-104): there no reflection or shadow ray can hit anything that blocks light
+ * (RayTracingFunctions.swift:241) or carries a material (:192, :245).  The bitmap and the hit ids are the
+ * same with and without the flag. */
+#define RTMI_FLAG_NO_RAY_STATISTICS 1
 
 /* Work and timing counters of one render call. */
 typedef struct {

@@ -13,7 +13,8 @@ from . import _abi, scenes  # noqa: F401
 from ._abi import Camera, Counters, Params, SceneDesc  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librtmi.so")
+# RTMI_LIB_PATH: another build of the library (kernel experiments); the default is the in-tree build
+LIB_PATH = os.environ.get("RTMI_LIB_PATH") or os.path.join(_HERE, "librtmi.so")
 _lib = None
 
 

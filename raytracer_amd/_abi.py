@@ -5,7 +5,7 @@ against the values the C compiler reports.
 """
 import ctypes as C
 
-RTMI_ABI_VERSION = 2
+RTMI_ABI_VERSION = 3
 
 RTMI_OK = 0
 RTMI_ERR_INVALID_ARGUMENT = -1
@@ -58,7 +58,7 @@ class Params(C.Structure):
                 ("ambient", D3), ("hit_policy", C.c_int32),
                 ("x0", C.c_int32), ("y0", C.c_int32), ("x1", C.c_int32), ("y1", C.c_int32),
                 ("tile_size", C.c_int32), ("tile_rank", C.c_int32), ("tile_world", C.c_int32),
-                ("search", C.c_int32)]
+                ("search", C.c_int32), ("flags", C.c_int32)]
 
 
 class Counters(C.Structure):
@@ -72,6 +72,8 @@ class Counters(C.Structure):
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved_"}
 
+
+RTMI_FLAG_NO_RAY_STATISTICS = 1
 
 RTMI_SEARCH_CONE_TREE = 0
 RTMI_SEARCH_LIST_SCAN = 1

@@ -12,6 +12,20 @@ constexpr int CONE_FLAG = 24;       // dword index of the batch's "always look c
 constexpr int EDGE_FLOATS = 9;      // per triangle: 3 scaled edge-plane vectors
 constexpr int GST2_FLOATS = 32;     // per triangle: plane (4) + bounds (5) + 3 x (w, e) (18), padded
 
+// A pointer that was loaded from a struct in device memory is a "generic" pointer to the compiler, and loads
+// through it are flat loads, which count against the LDS/scalar counter as well as the vector-memory one: every
+// wait for a scalar load then also waits for all of them.  Every such pointer of this library points to global
+// memory; as_global says so.  (The CPU build of the kernels has one address space.)
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class T>
+__device__ __forceinline__ T __attribute__((address_space(1)))* as_global(T* p) {
+  return (T __attribute__((address_space(1)))*)p;
+}
+#else
+template <class T>
+__device__ inline T* as_global(T* p) { return p; }
+#endif
+
 struct FrameConst {
   double ul[3], u[3], v[3], cam[3];
   double ppw_h, ppw_v, sub;

@@ -4,6 +4,10 @@
 // ---------------------------------------------------------------------------------------
 // top-level tests against spheres, bounding spheres and lights (FP64, list order)
 // ---------------------------------------------------------------------------------------
+// Per-lane work tallies of the shading kernels (rays, pairs); a lane serves a few hundred samples of a batch, so
+// 32 bits hold them, and they are widened when a wave adds its sum to the 64-bit counters.
+typedef unsigned int tally_t;
+
 struct Hit {
   d3 P, n;        // n is the unit normal, or (n_unit == 0) the un-normalised P - centre of a sphere
   double t;
@@ -65,7 +69,7 @@ __device__ inline TopTreeRef make_top_tree(const TopTreeArgs& a, const f2* rec, 
 // of k_pack_general follows, then rtx::tri_hit in FP64.  Called from divergent shading code: the
 // wave-level votes only see the lanes that are tracing.
 __device__ inline int top_tree_trace(const SceneDev& sc, const TopTreeRef& T, d3 o, d3 d, bool any_only, double* t_out,
-                                     d3* P_out, unsigned long long* n_tests) {
+                                     d3* P_out, tally_t* n_tests) {
   const float ox = (float)(o.x - sc.c0[0]), oy = (float)(o.y - sc.c0[1]), oz = (float)(o.z - sc.c0[2]);
   const float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
   const float ndo = -(dx * ox + dy * oy + dz * oz);
@@ -179,7 +183,7 @@ __device__ inline int top_tree_trace(const SceneDev& sc, const TopTreeRef& T, d3
       }
     }
   }
-  *n_tests += 8ull * leaf_visits;  // (ray, triangle) sphere tests this lane's ray took part in
+  *n_tests += 8u * leaf_visits;  // (ray, triangle) sphere tests this lane's ray took part in
   return best == 0x7fffffff ? -1 : best;
 }
 
@@ -187,7 +191,7 @@ __device__ inline int top_tree_trace(const SceneDev& sc, const TopTreeRef& T, d3
 // ray: intersections[0] if want_first, and whether any non-bounding object is hit.
 template <bool HAS_TOP>
 __device__ inline bool trace_top_secondary(const SceneDev& sc, const TopTreeRef& tt, d3 o, d3 d, bool want_first, Hit* h,
-                                           bool* any_non_bounding, unsigned long long* n_tests) {
+                                           bool* any_non_bounding, tally_t* n_tests) {
   bool found = false, anb = false;
   // spheres, bounding spheres and lights first, in list order: for a shadow ray the first
   // non-bounding hit settles the question and the triangles need not be searched

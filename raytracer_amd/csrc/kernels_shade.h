@@ -4,6 +4,15 @@
 // ---------------------------------------------------------------------------------------
 // k_shade: calculateLighting (RayTracingFunctions.swift:182-271) for every hit sample
 // ---------------------------------------------------------------------------------------
+#ifndef RTMI_SHADE_LEAN_WAVES
+#define RTMI_SHADE_LEAN_WAVES 4
+#endif
+constexpr int SHADE_LEAN_WAVES = RTMI_SHADE_LEAN_WAVES;  // resident waves per SIMD the lean shading kernel is compiled for
+#ifndef RTMI_SHADE_INERT_WAVES
+#define RTMI_SHADE_INERT_WAVES 5
+#endif
+constexpr int SHADE_INERT_WAVES = RTMI_SHADE_INERT_WAVES;
+
 struct RGBd {
   double r, g, b;
 };
@@ -18,18 +27,22 @@ struct ShadeConst {
 // For the usual small whole-number exponents (OBJ "Ns" values like 8) binary powering is used:
 // at most ceil(log2 n)+popcount roundings, i.e. a few ulp, far below what can change
 // UInt8(255 * c); every other exponent goes through the device pow().
-__device__ inline double spec_pow(double base, double e) {
-  if (e >= 1.0 && e <= 64.0 && e == floor(e)) {
-    int n = (int)e;
-    double r = 1.0, b = base;
-    bool first = true;
-    while (n) {
-      if (n & 1) { r = first ? b : r * b; first = false; }
-      n >>= 1;
-      if (n) b = b * b;
-    }
-    return r;
+__device__ inline bool spec_pow_is_small_integer(double e) { return e >= 1.0 && e <= 64.0 && e == floor(e); }
+
+__device__ inline double spec_pow_small_integer(double base, double e) {
+  int n = (int)e;
+  double r = 1.0, b = base;
+  bool first = true;
+  while (n) {
+    if (n & 1) { r = first ? b : r * b; first = false; }
+    n >>= 1;
+    if (n) b = b * b;
   }
+  return r;
+}
+
+__device__ inline double spec_pow(double base, double e) {
+  if (spec_pow_is_small_integer(e)) return spec_pow_small_integer(base, e);
   return pow(base, e);
 }
 
@@ -54,10 +67,20 @@ __device__ inline int count_facing_lights(const SceneDev& sc, d3 P, d3 n, bool n
   return c;
 }
 
-template <bool REFLECT, bool HAS_TOP>
+// LEAN (with REFLECT only): the instantiation for the common case that (1) the reflected ray finds nothing
+// whose lighting has to be evaluated -- no hit, a light, or an object without a material, whose contribution
+// is exactly zero (RTF:192, :245) -- and (2) the specular exponent is a small whole number.  It leaves the
+// nested light loop and the general pow() (forty-odd polynomial constants) out of the code, which is what
+// lets the kernel keep its registers for more resident waves.  Otherwise nothing is counted, *defer is set
+// and the caller hands the sample to the full instantiation.
+// INERT (with LEAN only): every member of the top-level list is a bounding sphere without a material, which is
+// what loadObjFile builds (ViewController.swift:101-104).  Nothing a reflection or shadow ray can do there
+// changes a pixel -- a bounding sphere blocks no light (RTF:241) and, lacking a material, reflects none
+// (RTF:192, :245) -- so the rays are neither traced nor counted (the caller asked for pixels, not for the
+// reference's ray statistics: RTMI_FLAG_NO_RAY_STATISTICS).
+template <bool REFLECT, bool HAS_TOP, bool LEAN = false, bool INERT = false>
 __device__ RGBd calculate_lighting(const SceneDev& sc, const TopTreeRef& tt, const ShadeConst& fc, const Hit& is, d3 camera,
-                                   unsigned long long* n_refl, unsigned long long* n_shadow,
-                                   unsigned long long* n_tests, unsigned long long* n_elided) {
+                                   tally_t* n_refl, tally_t* n_shadow, tally_t* n_tests, tally_t* n_elided, bool* defer = nullptr) {
   d3 surface_point = is.P;
   RGBd I = {0.0, 0.0, 0.0};
   const bool has_material = is.material >= 0;
@@ -68,6 +91,12 @@ __device__ RGBd calculate_lighting(const SceneDev& sc, const TopTreeRef& tt, con
     I.r = mat.Ka[0] * fc.ambient[0];
     I.g = mat.Ka[1] * fc.ambient[1];
     I.b = mat.Ka[2] * fc.ambient[2];
+    if constexpr (LEAN) {
+      if (is.has_normal && !spec_pow_is_small_integer(mat.Ns)) {
+        *defer = true;
+        return I;
+      }
+    }
   }
   if (!is.has_normal) return I;  // RTF:199-202
   if (!REFLECT && !has_material) {
@@ -88,9 +117,28 @@ __device__ RGBd calculate_lighting(const SceneDev& sc, const TopTreeRef& tt, con
     RGBd contribution = {0.0, 0.0, 0.0};
     Hit rh;
     bool anb;
-    *n_refl += 1;
-    if (trace_top_secondary<HAS_TOP>(sc, tt, surface_point, reflection, true, &rh, &anb, n_tests)) {
-      contribution = calculate_lighting<false, HAS_TOP>(sc, tt, fc, rh, surface_point, n_refl, n_shadow, n_tests, n_elided);
+    if constexpr (INERT) {
+      // contribution stays zero
+    } else if constexpr (LEAN) {
+      tally_t nt = 0;
+      if (trace_top_secondary<HAS_TOP>(sc, tt, surface_point, reflection, true, &rh, &anb, &nt)) {
+        if (rh.has_normal && rh.material >= 0) {
+          *defer = true;
+          return I;
+        }
+        if (rh.has_normal) {  // no material: its light loop adds nothing, its shadow rays are counted
+          const int c = count_facing_lights(sc, rh.P, rh.n, rh.n_unit);
+          *n_shadow += c;
+          *n_elided += c;
+        }
+      }
+      *n_refl += 1;
+      *n_tests += nt;
+    } else {
+      *n_refl += 1;
+      if (trace_top_secondary<HAS_TOP>(sc, tt, surface_point, reflection, true, &rh, &anb, n_tests)) {
+        contribution = calculate_lighting<false, HAS_TOP>(sc, tt, fc, rh, surface_point, n_refl, n_shadow, n_tests, n_elided);
+      }
     }
     I.r = I.r + contribution.r;
     I.g = I.g + contribution.g;
@@ -98,23 +146,29 @@ __device__ RGBd calculate_lighting(const SceneDev& sc, const TopTreeRef& tt, con
   }
 
   if (!has_material) {  // the light loop adds nothing (RTF:245); count its shadow rays
-    int c = count_facing_lights(sc, surface_point, normal, true);
-    *n_shadow += c;
-    *n_elided += c;
+    if constexpr (!INERT) {
+      int c = count_facing_lights(sc, surface_point, normal, true);
+      *n_shadow += c;
+      *n_elided += c;
+    }
     I.r = rtx::clamp01(I.r); I.g = rtx::clamp01(I.g); I.b = rtx::clamp01(I.b);  // RTF:269
     return I;
   }
 #pragma nounroll
   for (int li = 0; li < sc.n_lights; ++li) {  // RTF:226-268
+    // The light's nine values are fetched (scalar loads) where the loop uses them.  Without the barrier the
+    // compiler lifts the loads of every light out of the enclosing per-sample loop and then spills them.
     const rtmi_light& light = sc.lights[li];
     d3 point_to_light = rtx::normalize(rtx::sub(rtx::ld3(light.loc), surface_point));
     double ndl = rtx::dp(point_to_light, normal);
     if (ndl <= 0) continue;
-    Hit dummy;
-    bool anb = false;
-    *n_shadow += 1;
-    trace_top_secondary<HAS_TOP>(sc, tt, surface_point, point_to_light, false, &dummy, &anb, n_tests);
-    if (anb) continue;           // RTF:241
+    if constexpr (!INERT) {
+      Hit dummy;
+      bool anb = false;
+      *n_shadow += 1;
+      trace_top_secondary<HAS_TOP>(sc, tt, surface_point, point_to_light, false, &dummy, &anb, n_tests);
+      if (anb) continue;           // RTF:241
+    }
     if (!has_material) continue; // RTF:245
     double lr = light.diffuse[0], lg = light.diffuse[1], lb = light.diffuse[2];
     lr = ndl * lr; lg = ndl * lg; lb = ndl * lb;                    // scale(normalLightVectorDp)
@@ -123,7 +177,7 @@ __device__ RGBd calculate_lighting(const SceneDev& sc, const TopTreeRef& tt, con
     d3 light_reflection = rtx::normalize(rtx::sub(rtx::smul(2 * ndl, normal), point_to_light));  // RTF:251
     double rv = rtx::dp(light_reflection, surface_to_camera);
     if (rv <= 0) continue;  // RTF:255-257
-    double specular_term = spec_pow(rv, mat.Ns);  // RTF:259
+    double specular_term = LEAN ? spec_pow_small_integer(rv, mat.Ns) : spec_pow(rv, mat.Ns);  // RTF:259
     double sr = light.specular[0], sg = light.specular[1], sb = light.specular[2];
     sr = specular_term * sr; sg = specular_term * sg; sb = specular_term * sb;
     sr = mat.Ks[0] * sr; sg = mat.Ks[1] * sg; sb = mat.Ks[2] * sb;
@@ -136,7 +190,7 @@ __device__ RGBd calculate_lighting(const SceneDev& sc, const TopTreeRef& tt, con
 
 // Work tallies of a shading lane, summed per wave at the end of the kernel.
 struct ShadeTally {
-  unsigned long long n_refl = 0, n_shadow = 0, n_hit = 0, n_tests = 0, n_elided = 0;
+  tally_t n_refl = 0, n_shadow = 0, n_hit = 0, n_tests = 0, n_elided = 0;
 };
 
 __device__ inline void shade_tally_flush(DevCounters* cnt, const ShadeTally& t) {
@@ -148,9 +202,10 @@ __device__ inline void shade_tally_flush(DevCounters* cnt, const ShadeTally& t) 
 }
 
 // Shade sample s whose primary ray (direction d) hit `id` (triangle index, or -2 - object index);
-// t_tri is the triangle's intersection parameter.
-template <bool HAS_TOP>
-__device__ __forceinline__ void shade_sample(const ShadeConst& fc, const SceneDev& sc, const TopTreeRef& tt, int s, d3 d,
+// t_tri is the triangle's intersection parameter.  LEAN: returns true, with nothing counted or stored,
+// if the sample needs the full instantiation (see calculate_lighting).
+template <bool HAS_TOP, bool LEAN = false>
+__device__ __forceinline__ bool shade_sample(const ShadeConst& fc, const SceneDev& sc, const TopTreeRef& tt, int s, d3 d,
                                              int id, double t_tri, double* rgb, ShadeTally* tl) {
   d3 cam = rtx::ld3(fc.cam);
   Hit h;
@@ -185,12 +240,42 @@ __device__ __forceinline__ void shade_sample(const ShadeConst& fc, const SceneDe
   }
   RGBd c = {0.0, 0.0, 0.0};
   if (ok) {
+    bool defer = false;
+    static_assert(!LEAN, "the lean lighting needs a wave-uniform material: shade_triangle_lean");
+    c = calculate_lighting<true, HAS_TOP, false>(sc, tt, fc, h, cam, &tl->n_refl, &tl->n_shadow, &tl->n_tests, &tl->n_elided,
+                                                 &defer);
     tl->n_hit += 1;
-    c = calculate_lighting<true, HAS_TOP>(sc, tt, fc, h, cam, &tl->n_refl, &tl->n_shadow, &tl->n_tests, &tl->n_elided);
   }
   rgb[(size_t)s * 3 + 0] = c.r;
   rgb[(size_t)s * 3 + 1] = c.g;
   rgb[(size_t)s * 3 + 2] = c.b;
+  return false;
+}
+
+// The lean lighting (see calculate_lighting) of a triangle hit in a scene without top-level triangle runs.
+// Returns true, with nothing counted or stored, if the sample needs the full instantiation.
+template <bool INERT>
+__device__ __forceinline__ bool shade_triangle_lean(const ShadeConst& fc, const SceneDev& sc, const TopTreeRef& tt, int s, d3 d,
+                                                    int ti, double t_tri, double* rgb, ShadeTally* tl) {
+  const d3 cam = rtx::ld3(fc.cam);
+  const TriPlane pl = sc.planes[ti];
+  Hit h;
+  h.t = t_tri;
+  h.P = rtx::add(cam, rtx::smul(h.t, d));  // Renderables.swift:153: origin + intersectionParameter * direction
+  h.n = rtx::mk(pl.nx, pl.ny, pl.nz);
+  h.has_normal = 1;
+  h.n_unit = 1;
+  h.material = sc.tris[ti].material;
+  h.id = ti;
+  bool defer = false;
+  const RGBd c = calculate_lighting<true, false, true, INERT>(sc, tt, fc, h, cam, &tl->n_refl, &tl->n_shadow, &tl->n_tests, &tl->n_elided,
+                                                       &defer);
+  if (defer) return true;
+  tl->n_hit += 1;
+  rgb[(size_t)s * 3 + 0] = c.r;
+  rgb[(size_t)s * 3 + 1] = c.g;
+  rgb[(size_t)s * 3 + 2] = c.b;
+  return false;
 }
 
 // HAS_TOP: the scene lists triangles at top level, so secondary rays scan them (the code of
@@ -222,24 +307,29 @@ k_shade(ShadeConst fc, SceneDev sc, TopTreeArgs ta, const f2* __restrict__ trec,
 // triangle index goes to hit_id and the sample is shaded here, without a detour through the
 // shade queue.  t is evaluated once more (the same two operations, the same value).  Samples
 // without a hit keep the bounding object's marker in hit_id; k_resolve reads that as a miss.
-template <bool HAS_TOP>
-__global__ void __launch_bounds__(256, HAS_TOP ? 2 : 4)
+// Without top-level triangle runs the lean instantiation of the lighting runs here; the rare sample whose
+// reflected ray finds an object with a material goes to the shade queue (with its t), which k_shade serves
+// afterwards with the full instantiation.
+template <bool HAS_TOP, bool INERT = false>
+__global__ void __launch_bounds__(256, HAS_TOP ? 2 : (INERT ? SHADE_INERT_WAVES : SHADE_LEAN_WAVES))
 k_shade_candidates(ShadeConst fc, SceneDev sc, TopTreeArgs ta, const f2* __restrict__ trec, const float* __restrict__ gst2,
                    const int* __restrict__ tslot_pos, const SearchArgs* __restrict__ ap, double* rgb, int par) {
-  DevCounters* cnt = ap->cnt;
+  DevCounters* cnt = (DevCounters*)as_global(ap->cnt);
   const TopTreeRef tt = make_top_tree(ta, trec, gst2, tslot_pos);
   ShadeTally tl;
   if (!cnt->overflow) {
     const int list = blockIdx.x & (NSLOT - 1), part = blockIdx.x / NSLOT, parts = gridDim.x / NSLOT;
     const int list_cap = ap->cand_cap / NSLOT;
     const int n = min(cnt->cand_n[par][list][0], list_cap);
-    const int2* cand = ap->cand + (size_t)list * list_cap;
-    const double* dirs = ap->dirs;
+    const auto* cand = as_global(ap->cand) + (size_t)list * list_cap;
+    const auto* dirs = as_global(ap->dirs);
     // as in k_search_exact: the next step's entry and what hangs on it are fetched one step ahead
     const int stride = parts * blockDim.x;
-    const int* group = ap->group;
-    const int* best_pos = ap->best_pos;
-    int i = part * blockDim.x + threadIdx.x;
+    const auto* group = as_global(ap->group);
+    const auto* best_pos = as_global(ap->best_pos);
+    auto* hit_id = as_global(ap->hit_id);
+    auto* tval = as_global(ap->tval);
+    auto* q_shade = as_global(ap->q_shade);
     const int n_group = ap->n_group, n_samples = ap->n_samples, n_tris = ap->n_tris;
     auto entry = [&](int k) {  // candidate k with both indices range-checked
       int2 e = cand[k];
@@ -247,21 +337,47 @@ k_shade_candidates(ShadeConst fc, SceneDev sc, TopTreeArgs ta, const f2* __restr
       e.y = checked(e.y, n_group, cnt, 10);
       return e;
     };
+    // every lane of the workgroup makes the same number of steps (the votes below see whole waves)
+    int i = part * blockDim.x + threadIdx.x;
     int2 c = i < n ? entry(i) : make_int2(0, 0);
     int ti = i < n ? checked(group[c.y], n_tris, cnt, 11) : 0;
-    int bp = i < n ? best_pos[c.x] : 0;
-    while (i < n) {
+    int bp = i < n ? best_pos[c.x] : -1;
+    for (int base = part * blockDim.x; base < n; base += stride) {
       const int inext = i + stride;
-      const int2 cn = inext < n ? entry(inext) : c;
-      const int tin = checked(group[cn.y], n_tris, cnt, 11);
-      const int bpn = best_pos[cn.x];
+      const int2 cn = inext < n ? entry(inext) : make_int2(0, 0);
+      const int tin = inext < n ? checked(group[cn.y], n_tris, cnt, 11) : 0;
+      const int bpn = inext < n ? best_pos[cn.x] : -1;
       const int s = c.x;
-      if (bp == c.y) {  // else another triangle of this ray is listed earlier, or the pair was no hit
-        const double* dp = dirs + (size_t)s * 3;
-        const d3 d = rtx::mk(dp[0], dp[1], dp[2]);
-        const double tv = rtx::tri_t(sc.planes[ti], rtx::ld3(fc.cam), d);  // k_search_exact accepted this pair
-        ap->hit_id[s] = ti;
-        shade_sample<HAS_TOP>(fc, sc, tt, s, d, ti, tv, rgb, &tl);
+      bool deferred = false;
+      double tv = 0.0;
+      const bool want = i < n && bp == c.y;  // else another triangle of this ray is listed earlier, or the pair was no hit
+      d3 d = rtx::mk(0.0, 0.0, 0.0);
+      if (want) {
+        const auto* dp = dirs + (size_t)s * 3;
+        d = rtx::mk(dp[0], dp[1], dp[2]);
+        tv = rtx::tri_t(sc.planes[ti], rtx::ld3(fc.cam), d);  // k_search_exact accepted this pair
+        hit_id[s] = ti;
+      }
+      if constexpr (HAS_TOP) {
+        if (want) shade_sample<true>(fc, sc, tt, s, d, ti, tv, rgb, &tl);
+      } else {
+        if (want) deferred = shade_triangle_lean<INERT>(fc, sc, tt, s, d, ti, tv, rgb, &tl);
+      }
+      if constexpr (!HAS_TOP) {
+        // samples that need the full lighting go to the shade queue, one atomic per wave and step; every
+        // sample is queued at most once per frame, so the queue (one entry per sample) cannot overflow
+        const unsigned long long dm = __ballot(deferred);
+        if (dm) {
+          const int lane = threadIdx.x & 63;
+          const int leader = __ffsll((long long)dm) - 1;
+          int qb = 0;
+          if (lane == leader) qb = atomicAdd(&cnt->q_shade, __popcll(dm));
+          qb = __shfl(qb, leader);
+          if (deferred) {
+            tval[s] = tv;
+            q_shade[qb + __popcll(dm & ((1ull << lane) - 1ull))] = s;
+          }
+        }
       }
       c = cn;
       ti = tin;

@@ -220,14 +220,17 @@ k_search_exact(const SearchArgs* __restrict__ ap, int parity) {
     const int list = blockIdx.x & (NSLOT - 1), part = blockIdx.x / NSLOT, parts = gridDim.x / NSLOT;
     const int list_cap = ap->cand_cap / NSLOT;
     const int n = min(cnt->cand_n[parity][list][0], list_cap);
-    const int2* cand = ap->cand + (size_t)list * list_cap;
-    const double* dirs = ap->dirs;
+    const auto* cand = as_global(ap->cand) + (size_t)list * list_cap;
+    const auto* dirs = as_global(ap->dirs);
+    const auto* tris = as_global(ap->tris);
+    const auto* planes = as_global(ap->planes);
+    auto* best_pos = as_global(ap->best_pos);
     const d3 o = rtx::ld3(ap->cam);
     // The entry of the NEXT step is fetched (with the triangle index it leads to) before the
     // current one is evaluated: a step begins with a chain of dependent loads, and this way the
     // chain of step k+1 runs under the arithmetic of step k.
     const int stride = parts * blockDim.x;
-    const int* group = ap->group;
+    const auto* group = as_global(ap->group);
     int i = part * blockDim.x + threadIdx.x;
     DevCounters* wcnt = ap->cnt;
     const int n_group = ap->n_group, n_samples = ap->n_samples, n_tris = ap->n_tris;
@@ -244,14 +247,17 @@ k_search_exact(const SearchArgs* __restrict__ ap, int parity) {
       const int2 cn = inext < n ? entry(inext) : c;
       const int tin = checked(group[cn.y], n_tris, wcnt, 8);
       const int s = c.x, pos = c.y;
-      const double* dp = dirs + (size_t)s * 3;
-      const rtmi_triangle& tr = ap->tris[ti];
+      const auto* dp = dirs + (size_t)s * 3;
+      const auto* tv0 = &tris[ti].v[0][0];  // nine doubles: the three vertices
+      const auto* plp = planes + ti;
+      TriPlane pl;
+      pl.nx = plp->nx; pl.ny = plp->ny; pl.nz = plp->nz; pl.c = plp->c;
       d3 P;
       double tv;
       n_exact += 1;
-      if (rtx::tri_hit(rtx::ld3(tr.v[0]), rtx::ld3(tr.v[1]), rtx::ld3(tr.v[2]), ap->planes[ti], o,
+      if (rtx::tri_hit(rtx::mk(tv0[0], tv0[1], tv0[2]), rtx::mk(tv0[3], tv0[4], tv0[5]), rtx::mk(tv0[6], tv0[7], tv0[8]), pl, o,
                        rtx::mk(dp[0], dp[1], dp[2]), &tv, &P))
-        atomicMin(&ap->best_pos[s], pos);
+        atomicMin((int*)&best_pos[s], pos);
       c = cn;
       ti = tin;
       i = inext;

@@ -247,6 +247,13 @@ struct rtmi_scene {
   std::array<int, 9> blocks_key{};     // frame geometry + tile selection it was built for
   bool blocks_valid = false;
   int n_plain_shadeable = 0;  // spheres and lights in the object list (hits on them go through the shade queue)
+  // whether the lean shading of k_shade_candidates can hand a sample to the shade queue: a sphere or bounding
+  // sphere with a material exists (a reflected ray may find it), or a material whose specular exponent is not
+  // a small whole number
+  bool lean_may_defer = false;
+  // every member of the top-level list is a bounding sphere without a material (what loadObjFile builds):
+  // no reflection or shadow ray can change a pixel
+  bool inert_secondary = false;
   int exact_grid = 2048;  // workgroups of the grid-stride k_search_exact: eight per compute unit
   // one frame may be in flight between rtmi_render_begin and rtmi_render_end
   bool pending = false;
@@ -463,6 +470,10 @@ static int32_t scene_create_impl(const rtmi_scene_desc* desc, int32_t device, rt
   HIP_TRY(hipEventCreate(&sc->ev_c));
   HIP_TRY(hipEventCreate(&sc->ev_d));
 
+  for (int32_t m = 0; m < desc->n_materials; ++m) {
+    const double ns = desc->materials[m].Ns;
+    if (!(ns >= 1.0 && ns <= 64.0 && ns == floor(ns))) sc->lean_may_defer = true;  // spec_pow_is_small_integer
+  }
   sc->objects.assign(desc->objects, desc->objects + desc->n_objects);
   sc->h_lights.assign(desc->lights, desc->lights + desc->n_lights);
   sc->n_lights = desc->n_lights;
@@ -501,6 +512,7 @@ static int32_t scene_create_impl(const rtmi_scene_desc* desc, int32_t device, rt
     } else {
       ++n_sphere_like;
       if (ob.kind != RTMI_BOUNDING_SPHERE) ++sc->n_plain_shadeable;
+      if (ob.kind != RTMI_LIGHT && ob.material >= 0) sc->lean_may_defer = true;
       if (ob.kind == RTMI_BOUNDING_SPHERE) {
         TriGroup g;
         g.object = (int)k;
@@ -511,6 +523,9 @@ static int32_t scene_create_impl(const rtmi_scene_desc* desc, int32_t device, rt
       }
     }
   }
+  sc->inert_secondary = desc->n_objects > 0;
+  for (int64_t k = 0; k < desc->n_objects; ++k)
+    if (desc->objects[k].kind != RTMI_BOUNDING_SPHERE || desc->objects[k].material >= 0) sc->inert_secondary = false;
   // a top-level triangle that appears in two runs would need per-position owners
   {
     std::vector<int> sorted = top;
@@ -725,6 +740,7 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
   }
   if (p->hit_policy != RTMI_HIT_LIST_ORDER) return RTMI_ERR_UNSUPPORTED;
   if (p->search != RTMI_SEARCH_CONE_TREE && p->search != RTMI_SEARCH_LIST_SCAN) return RTMI_ERR_INVALID_ARGUMENT;
+  if (p->flags & ~RTMI_FLAG_NO_RAY_STATISTICS) return RTMI_ERR_INVALID_ARGUMENT;
   const bool use_tree = p->search == RTMI_SEARCH_CONE_TREE;
   int spp = rtmi_samples_per_pixel(p->pixel_subdivision);
   if (spp < 0) return spp;
@@ -1022,10 +1038,17 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
         HIP_TRY(hipEventRecord(ev[1], st));
         if (gi == 0)
           hipLaunchKernelGGL(k_search_finish, dim3(grid), dim3(256), 0, st, sc->d_sargs + gi, par);
-        else
-          hipLaunchKernelGGL(has_top_runs ? k_shade_candidates<true> : k_shade_candidates<false>, dim3(sc->exact_grid), dim3(256),
-                             0, st, shc, sc->dev, sc->top_args, (const f2*)sc->d_trec, (const float*)sc->d_gst2,
-                             (const int*)sc->groups[0].d_slot_pos, sc->d_sargs + gi, sc->wb.rgb, par);
+        else {
+          // pixels only, and a scene whose secondary rays cannot change one: the instantiation without them
+          const bool inert = sc->inert_secondary && (p->flags & RTMI_FLAG_NO_RAY_STATISTICS) != 0;
+#define RTMI_LAUNCH_SHADE_CANDIDATES(kernel)                                                                              \
+  hipLaunchKernelGGL(kernel, dim3(sc->exact_grid), dim3(256), 0, st, shc, sc->dev, sc->top_args, (const f2*)sc->d_trec, \
+                     (const float*)sc->d_gst2, (const int*)sc->groups[0].d_slot_pos, sc->d_sargs + gi, sc->wb.rgb, par)
+          if (has_top_runs) RTMI_LAUNCH_SHADE_CANDIDATES((k_shade_candidates<true, false>));
+          else if (inert) RTMI_LAUNCH_SHADE_CANDIDATES((k_shade_candidates<false, true>));
+          else RTMI_LAUNCH_SHADE_CANDIDATES((k_shade_candidates<false, false>));
+#undef RTMI_LAUNCH_SHADE_CANDIDATES
+        }
       } else {
         hipLaunchKernelGGL(scan_kernel, dim3(search_grid), dim3(256), 0, st, sc->d_sargs + gi, (const f2*)g.d_cone);
         HIP_TRY(hipEventRecord(ev[1], st));
@@ -1042,8 +1065,9 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
     for (size_t gi = 1; gi < sc->groups.size(); ++gi)
       if ((rc = search_group(gi))) return rc;
     // the shade queue stays empty when the cone tree shades every triangle hit itself and the scene
-    // lists nothing else that can be shaded (no sphere or light object, no top-level triangles)
-    if (!(use_tree && !has_top_runs && sc->n_plain_shadeable == 0)) {
+    // lists nothing else that can be shaded (no sphere or light object, no top-level triangles) and
+    // nothing with a material that a reflected ray could find (k_shade_candidates queues those samples)
+    if (!(use_tree && !has_top_runs && sc->n_plain_shadeable == 0 && !sc->lean_may_defer)) {
       if (b0 == 0) HIP_TRY(hipEventRecord(sc->ev_c, st));  // timed for the first batch only (frames are one batch as a rule)
       hipLaunchKernelGGL(has_top_runs ? k_shade<true> : k_shade<false>, dim3(std::min(grid, 4 * sc->exact_grid)), dim3(256), 0, st, shc, sc->dev, sc->top_args, (const f2*)sc->d_trec,
                          (const float*)sc->d_gst2, (const int*)sc->groups[0].d_slot_pos, sc->wb.dirs, sc->wb.tval, sc->wb.q_shade, &sc->wb.cnt->q_shade,

@@ -19,7 +19,7 @@ SEARCHES = {"tree": _abi.RTMI_SEARCH_CONE_TREE, "scan": _abi.RTMI_SEARCH_LIST_SC
 PARITY_COUNTERS = ("samples", "rays_reflection", "rays_shadow", "sphere_tests", "primary_hits")
 # kernels whose wave-level votes are meant to be reached by part of a wave (the secondary-ray tree walk is
 # called from divergent shading code); everywhere else a vote that misses live lanes is a defect
-DIVERGENT_OK = ("k_shade<true>", "k_shade_candidates<true>")
+DIVERGENT_OK = ("k_shade<true>", "k_shade_candidates<true, false>")
 
 
 @pytest.fixture(scope="module")
@@ -295,3 +295,39 @@ def test_emulated_kernels_have_no_data_races(emu, oracle_mod, tmp_path):
     with ThreadPoolExecutor(8) as pool:
         for case, reports in zip(RACE_CASES, pool.map(one, enumerate(RACE_CASES))):
             assert not reports, (case, reports[:3])
+
+
+def test_emulated_lean_shading_hands_over_to_the_full_kernel(emu, oracle_mod, tmp_path):
+    """k_shade_candidates shades with the lean instantiation and queues what it cannot finish: a material with a
+    fractional specular exponent (no sphere in the scene, so nothing else fills the shade queue), and a reflected
+    ray that finds a sphere with a material."""
+    data = scenes.mesh_scene(1, "B", 2, bounding_sphere=oracle_mod.bounding_sphere)
+    data.materials = scenes.material(Ns=3.5, d=1.0, illum=2, Kd=(0.8, 0.3, 0.2), Ka=(0.2, 0.5, 0.9), Ks=(0.4, 0.9, 0.1))
+    cam = scenes.make_camera(**scenes.MESH_CAMERA)
+    run_case(emu, oracle_mod, tmp_path / "ns", data, [cam], scenes.make_params(40, 32, 0.5), searches=("tree",))
+    data = scenes.mesh_scene(1, "B", 2, bounding_sphere=oracle_mod.bounding_sphere)
+    data.objects = np.concatenate([data.objects, scenes.sphere_object((1.9, 0.3, 0.4), 0.7, 0)])
+    run_case(emu, oracle_mod, tmp_path / "sphere", data, [cam], scenes.make_params(48, 32, 0.5), searches=("tree",))
+
+
+def test_emulated_pixels_only_flag_gives_the_same_frame(emu, oracle_mod, tmp_path):
+    """RTMI_FLAG_NO_RAY_STATISTICS on a scene of bounding spheres without material (what loadObjFile builds): the
+    shading instantiation without secondary rays runs; bitmap and hit ids equal the oracle's, no secondary ray
+    is counted.  On a scene with a sphere that has a material the flag changes nothing."""
+    cam = scenes.make_camera(**scenes.MESH_CAMERA)
+    data = scenes.mesh_scene(1, "B", 3, bounding_sphere=oracle_mod.bounding_sphere)
+    p = scenes.make_params(40, 32, 0.5, flags=_abi.RTMI_FLAG_NO_RAY_STATISTICS)
+    o_rgba, o_hit, o_cnt = oracle_mod.render(data, cam, scenes.make_params(40, 32, 0.5), threads=4)
+    frames, stats, _ = emu.run_emulated(data, [cam, cam], p, tmp_path / "inert")
+    for rgba, hit, cnt in frames:
+        assert (hit[:31, :39] == o_hit[:31, :39]).all() and (rgba[:31, :39] == o_rgba[:31, :39]).all()
+        assert cnt.primary_hits == o_cnt["primary_hits"] > 0
+        assert cnt.rays_reflection == 0 and cnt.rays_shadow == 0 and cnt.shadow_rays_elided == 0
+    assert any("k_shade_candidates<false, true>" in k for k in stats)
+    data.objects = np.concatenate([data.objects, scenes.sphere_object((1.9, 0.3, 0.4), 0.7, 0)])
+    o_rgba, o_hit, o_cnt = oracle_mod.render(data, cam, scenes.make_params(40, 32, 0.5), threads=4)
+    frames, stats, _ = emu.run_emulated(data, [cam], p, tmp_path / "not_inert")
+    rgba, hit, cnt = frames[0]
+    assert (hit[:31, :39] == o_hit[:31, :39]).all() and (rgba[:31, :39] == o_rgba[:31, :39]).all()
+    assert cnt.rays_reflection == o_cnt["rays_reflection"] and cnt.rays_shadow == o_cnt["rays_shadow"]
+    assert not any("k_shade_candidates<false, true>" in k for k in stats)

@@ -545,3 +545,27 @@ def test_wait_event_orders_the_scene_stream_after_the_callers_fill(oracle_mod, r
         assert (got[:239, :319] == expect[:239, :319]).all()
         assert (got[239] == 0x33).all() and (got[:, 319] == 0x33).all()  # unrendered pixels keep the caller's bytes
     sc.close()
+
+
+def test_pixels_only_flag_gives_the_same_frame_without_secondary_rays(oracle_mod, rt):
+    """RTMI_FLAG_NO_RAY_STATISTICS: same bitmap and hit ids; on a scene of bounding spheres without material no
+    secondary ray is traced or counted, on any other scene the flag changes nothing."""
+    cam = scenes.make_camera(**scenes.MESH_CAMERA)
+    for extra_sphere in (False, True):
+        data = scenes.mesh_scene(3, "B", 3, bounding_sphere=rt.bounding_sphere)
+        if extra_sphere:
+            data.objects = np.concatenate([data.objects, scenes.sphere_object((1.9, 0.3, 0.4), 0.7, 0)])
+        o_rgba, o_hit, o_cnt = oracle_mod.render(data, cam, scenes.make_params(200, 160, 0.5), threads=16)
+        sc = rt.Scene(data)
+        for search in (_abi.RTMI_SEARCH_CONE_TREE, _abi.RTMI_SEARCH_LIST_SCAN):
+            p = scenes.make_params(200, 160, 0.5, search=search, flags=_abi.RTMI_FLAG_NO_RAY_STATISTICS)
+            g_rgba, g_hit, g_cnt = sc.render(cam, p)
+            assert (g_hit == o_hit).all() and (g_rgba == o_rgba).all()
+            assert g_cnt["primary_hits"] == o_cnt["primary_hits"]
+            if extra_sphere or search == _abi.RTMI_SEARCH_LIST_SCAN:
+                assert g_cnt["rays_reflection"] == o_cnt["rays_reflection"] and g_cnt["rays_shadow"] == o_cnt["rays_shadow"]
+            else:
+                assert g_cnt["rays_reflection"] == 0 and g_cnt["rays_shadow"] == 0
+        sc.close()
+    with pytest.raises(rt.RtmiError):
+        rt.Scene(scenes.two_sphere_scene()).render(scenes.make_camera(**scenes.VC_CAMERA), scenes.make_params(32, 32, flags=6))
