@@ -45,6 +45,8 @@ struct FrameConst {
   float base_f[3];
   int n_genf;
   int tile_size, tiles_x, tile_rank, tile_world;
+  // per entry of the block list: 0 = no sample of the block can hit anything (k_block_cull); null = every block is live
+  const unsigned char* block_live;
 };
 
 // Work counters are striped over NSLOT cache lines (one 64-byte line per slot) so that the

@@ -10,6 +10,42 @@
 // every rendered sample goes on to the top-level triangle search, which resolves it.
 constexpr int GEN_ITERS = 8;  // samples per thread in k_gen; a workgroup covers 2048 consecutive samples
 
+// One thread per 8x8 pixel block: can any sample of the block come near any sphere-like object?  The sample
+// positions of a block lie within 4 pixels of its centre in both directions, so their focal-plane points lie
+// within rho = 4/pixelsPerWorldHorizontal + 4/pixelsPerWorldVertical of the centre's (u and v are unit vectors,
+// WorldCoordinateSequence.swift:62-66), and a direction d = p - camera deviates from the centre's direction dc by
+// an angle phi with sin(phi) <= rho/|dc|.  With theta the angle between dc and the unit vector g towards an
+// object's centre, no direction of the block makes a smaller angle with g than theta - phi; the block is cleared
+// for the object if cos(theta - phi) stays below the cosine the per-sample pre-test of k_gen demands (whose
+// margin covers the rounding here, FP64, many times over).  A cleared block is never touched by k_gen and
+// written as black by k_resolve.
+__global__ void __launch_bounds__(256)
+k_block_cull(FrameConst fc, const int2* __restrict__ blocks, int nblocks, unsigned char* block_live) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nblocks) return;
+  const int2 bc = blocks[b];
+  const double ic = bc.x * BLK + 0.5 * BLK, jc = bc.y * BLK + 0.5 * BLK;
+  const double hu = ic / fc.ppw_h, hv = jc / fc.ppw_v;
+  const double dx = (fc.ul[0] - fc.cam[0]) + fc.u[0] * hu - fc.v[0] * hv;
+  const double dy = (fc.ul[1] - fc.cam[1]) + fc.u[1] * hu - fc.v[1] * hv;
+  const double dz = (fc.ul[2] - fc.cam[2]) + fc.u[2] * hu - fc.v[2] * hv;
+  const double len = sqrt(dx * dx + dy * dy + dz * dz);
+  const double rho = 1.001 * (0.5 * BLK / fabs(fc.ppw_h) + 0.5 * BLK / fabs(fc.ppw_v));
+  bool live = !(len > 4.0 * rho);  // a patch that is wide as seen from the camera (or a NaN) is not cleared
+  if (!live) {
+    const double sphi = rho / len, cphi = sqrt(1.0 - sphi * sphi);
+    for (int o = 0; o < fc.n_genf && !live; ++o) {
+      const float4 gf = fc.genf[o];
+      if (!(gf.w > 0.0f)) { live = true; break; }  // this object is never cleared
+      const double ct = ((double)gf.x * dx + (double)gf.y * dy + (double)gf.z * dz) / len;
+      const double st = sqrt(fmax(0.0, 1.0 - ct * ct));
+      const double cu = ct >= cphi ? 1.0 : ct * cphi + st * sphi;  // largest cosine to g over the block
+      live = !(cu < sqrt((double)gf.w));
+    }
+  }
+  block_live[b] = live ? 1 : 0;
+}
+
 __global__ void __launch_bounds__(256)
 k_gen(FrameConst fc, SceneDev sc, const int2* __restrict__ blocks, int nsamples, int* hit_id, double* dirs,
       int* q_child, int* q_shade, int* q_top, DevCounters* cnt) {
@@ -27,11 +63,14 @@ k_gen(FrameConst fc, SceneDev sc, const int2* __restrict__ blocks, int nsamples,
     const int s = (t << 6) + lane;
     int x = 0, y = 0, kx = 0, ky = 0;
     bool live = false;
+    bool dead_block = false;  // wave-uniform
     if ((t << 6) < nsamples) {  // nsamples is a multiple of 64
       int b;
       group_coords(fc, t, &b, &kx, &ky);
-      live = pixel_coords(fc, blocks, b, lane, &x, &y);
+      dead_block = fc.block_live && fc.block_live[b] == 0;
+      if (!dead_block) live = pixel_coords(fc, blocks, b, lane, &x, &y);
     }
+    if (dead_block) continue;  // nothing of this block is written or queued; k_resolve knows
     int id = -1;
     bool to_child = false, to_shade = false;
     if (live && fc.n_genf > 0) {

@@ -402,6 +402,14 @@ k_resolve(FrameConst fc, const int2* __restrict__ blocks, int npix, const int* _
   int b = p >> 6, pix = p & (BLK_PIX - 1);
   int x, y;
   if (!pixel_coords(fc, blocks, b, pix, &x, &y)) return;
+  if (fc.block_live && fc.block_live[b] == 0) {
+    // no sample of this block can hit anything (k_block_cull; k_gen left its samples alone): every sample is
+    // RGB.black, the average is black and UInt8(255 * 0) = 0
+    *reinterpret_cast<unsigned int*>(rgba + (size_t)4 * fc.W * y + (size_t)x * 4) = 255u << 24;
+    if (hit_out)
+      for (int q = 0; q < fc.spp; ++q) hit_out[((size_t)y * fc.W + x) * fc.spp + q] = -1;
+    return;
+  }
   double cr = 0.0, cg = 0.0, cb = 0.0;  // cumulative = RGB(0,0,0), Utilities.swift:56
   for (int q = 0; q < fc.spp; ++q) {
     int s = ((b * fc.spp + q) << 6) + pix;

@@ -113,6 +113,7 @@ struct WorkBufs {
   double* tabs = nullptr;    // utab then vtab (FP64), then their FP32 copies
   size_t cap_tabs = 0;
   int2* blocks = nullptr;
+  unsigned char* block_live = nullptr;  // per block of the list: can any of its samples hit anything (k_block_cull)
   size_t cap_blocks = 0;
   DevCounters* cnt = nullptr;  // work counters, queue and list fill levels
 };
@@ -143,7 +144,7 @@ constexpr size_t scratch_bytes_needed() {
   return 6 * align256(sizeof(int) * NOALLOC_MAX_SAMPLES) + 2 * align256(sizeof(double) * 3 * NOALLOC_MAX_SAMPLES) +
          align256(sizeof(double) * NOALLOC_MAX_SAMPLES) + align256(sizeof(int2) * NOALLOC_CAND) +
          align256((sizeof(double) + sizeof(float)) * 3 * NOALLOC_TAB_ENTRIES) + align256(sizeof(int2) * NOALLOC_BLOCKS) +
-         align256(sizeof(DevCounters));
+         align256(NOALLOC_BLOCKS) + align256(sizeof(DevCounters));
 }
 static_assert(scratch_bytes_needed() <= SCRATCH_BYTES, "the static array is too small for its slices");
 
@@ -171,6 +172,7 @@ static WorkBufs carve_scratch(unsigned char* base) {
   w.tabs = (double*)take((sizeof(double) + sizeof(float)) * 3 * NOALLOC_TAB_ENTRIES);
   w.cap_tabs = 3 * NOALLOC_TAB_ENTRIES;
   w.blocks = (int2*)take(sizeof(int2) * NOALLOC_BLOCKS);
+  w.block_live = (unsigned char*)take(NOALLOC_BLOCKS);
   w.cap_blocks = NOALLOC_BLOCKS;
   w.cnt = (DevCounters*)take(sizeof(DevCounters));
   return w;
@@ -427,7 +429,7 @@ extern "C" void rtmi_scene_destroy(rtmi_scene* sc) {
   (void)hipFree(sc->wb.hit_id); (void)hipFree(sc->wb.tri_hit); (void)hipFree(sc->wb.q_child);
   (void)hipFree(sc->wb.q_shade); (void)hipFree(sc->wb.q_top); (void)hipFree(sc->wb.rgb);
   (void)hipFree(sc->wb.dirs); (void)hipFree(sc->wb.tval); (void)hipFree(sc->wb.best_pos); (void)hipFree(sc->wb.cand); (void)hipFree(sc->wb.tabs); (void)hipFree(sc->d_sargs); (void)hipFree(sc->d_genf);
-  (void)hipFree(sc->wb.blocks); (void)hipFree(sc->wb.cnt);
+  (void)hipFree(sc->wb.blocks); (void)hipFree(sc->wb.block_live); (void)hipFree(sc->wb.cnt);
   if (sc->h_cnt) (void)hipHostFree(sc->h_cnt);
   for (auto& tr : sc->ev_pool) for (hipEvent_t e : tr) (void)hipEventDestroy(e);
   if (sc->ev_a) (void)hipEventDestroy(sc->ev_a);
@@ -671,10 +673,13 @@ static int32_t ensure_buffers(rtmi_scene* sc, size_t samples, size_t blocks) {
   }
   if (blocks > sc->wb.cap_blocks) {
     (void)hipFree(sc->wb.blocks);
+    (void)hipFree(sc->wb.block_live);
     sc->wb.blocks = nullptr;
+    sc->wb.block_live = nullptr;
     sc->wb.cap_blocks = 0;
     sc->blocks_valid = false;
     HIP_TRY(hipMalloc(&sc->wb.blocks, sizeof(int2) * blocks));
+    HIP_TRY(hipMalloc(&sc->wb.block_live, blocks));
     sc->wb.cap_blocks = blocks;
   }
   return RTMI_OK;
@@ -925,6 +930,14 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
     sc->blocks_key = blocks_key;
     sc->blocks_valid = true;
   }
+  // blocks none of whose samples can come near any object (same operands as k_gen's pre-test): every frame,
+  // the test is one thread per block
+  fc.block_live = nullptr;
+  if (fc.n_genf > 0 && !blocks.empty()) {
+    hipLaunchKernelGGL(k_block_cull, dim3((unsigned)((blocks.size() + 255) / 256)), dim3(256), 0, st, fc,
+                       (const int2*)sc->wb.blocks, (int)blocks.size(), sc->wb.block_live);
+    fc.block_live = sc->wb.block_live;
+  }
 
   // Per-frame preparation that depends only on the camera and the frame geometry is kept from the
   // previous frame when those are unchanged (a viewer that re-renders with other lights, or a
@@ -1014,9 +1027,11 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
     size_t nb = std::min(blocks_per_batch, blocks.size() - b0);
     int nsamples = (int)(nb * samples_per_block);
     const int2* d_blk = sc->wb.blocks + b0;
+    FrameConst fcb = fc;  // the block indices of a batch's kernels count from the batch's first block
+    if (fc.block_live) fcb.block_live = fc.block_live + b0;
     if (b0 > 0) HIP_TRY(hipMemsetAsync(&sc->wb.cnt->q_child, 0, sizeof(int) * 3, st));  // the first batch starts from the cleared counters
     int grid = (nsamples + 255) / 256;
-    hipLaunchKernelGGL(k_gen, dim3((nsamples + 256 * GEN_ITERS - 1) / (256 * GEN_ITERS)), dim3(256), 0, st, fc, sc->dev, d_blk, nsamples, sc->wb.hit_id, sc->wb.dirs, sc->wb.q_child,
+    hipLaunchKernelGGL(k_gen, dim3((nsamples + 256 * GEN_ITERS - 1) / (256 * GEN_ITERS)), dim3(256), 0, st, fcb, sc->dev, d_blk, nsamples, sc->wb.hit_id, sc->wb.dirs, sc->wb.q_child,
                        sc->wb.q_shade, sc->wb.q_top, sc->wb.cnt);
     const int SR = search_rays_per_lane();
     const int search_grid = (nsamples + 256 * SR - 1) / (256 * SR);
@@ -1076,7 +1091,7 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
       shade_queue_launched = true;
     }
     int npix = (int)(nb * BLK_PIX);
-    hipLaunchKernelGGL(k_resolve, dim3((npix + 255) / 256), dim3(256), 0, st, fc, d_blk, npix, sc->wb.hit_id, sc->wb.rgb,
+    hipLaunchKernelGGL(k_resolve, dim3((npix + 255) / 256), dim3(256), 0, st, fcb, d_blk, npix, sc->wb.hit_id, sc->wb.rgb,
                        (const rtmi_object*)sc->d_objects, sc->dev.n_objects, sc->wb.cnt, (unsigned char*)rgba_dev, (int*)hit_dev);
     HIP_TRY(hipGetLastError());
   }

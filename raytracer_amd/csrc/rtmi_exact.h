@@ -170,8 +170,11 @@ RT_HD bool sphere_any(d3 location, double radius, d3 origin, d3 direction) {
   double a = -dp(direction, center_to_eye);
   double delta = a * a - (len_squared(center_to_eye) - radius_squared);
   if (!(delta >= 0)) return false;
-  double sqrtdelta = sqrt(delta);
   if (delta == 0) return a >= 0.0000001;
+  // t1 = a + sqrt(delta) is at least a (the root is not negative and rounding is monotonic): with a itself
+  // past the threshold -- the sphere's centre lies ahead of the origin -- the answer needs no square root
+  if (a >= 0.0000001) return true;
+  double sqrtdelta = sqrt(delta);
   double t1 = a + sqrtdelta, t2 = a - sqrtdelta;
   return t1 >= 0.0000001 || t2 >= 0.0000001;
 }
