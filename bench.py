@@ -1,13 +1,17 @@
 #!/usr/bin/env python3
 """Benchmark of the render hot path on MI355X.
 
-A step is one full frame of the headline configuration: the stand-in "pig" mesh (5,120-triangle
-displaced icosphere wrapped in Sphere(boundingObjects:), i.e. form B, what the reference's
-loadObjFile builds), 3840x2160, 16 samples per pixel (pixelSubdivision 0.25), 3 lights, shadow and
-reflection rays, reference-exact list-order hit policy.  With N > 1 the frame's 32x32 tiles are
-dealt cyclically over the ranks (strong scaling: total work per step is fixed), the scene is
-broadcast once over RCCL before the timed region and every rank's own pixels are gathered on rank 0
-inside it.
+A step is one full frame of the headline configuration: the stand-in "pig" mesh (5,120-triangle displaced icosphere
+wrapped in Sphere(boundingObjects:), i.e. form B, what the reference's loadObjFile builds), 3840x2160, 16 samples per
+pixel (pixelSubdivision 0.25), 3 lights, reference-exact list-order hit policy, the camera moving every step on the
+orbit of config 5 (--static-camera holds it still).  Timed frames ask for pixels only (RTMI_FLAG_NO_RAY_STATISTICS):
+rays that cannot change a pixel are neither traced nor counted.  With N > 1 the frame's 32x32 tiles are dealt
+cyclically over the ranks (strong scaling: total work per step is fixed), the scene is broadcast once over RCCL before
+the timed region and every rank's own pixels are gathered on rank 0 inside it.
+
+`value` = rays actually traced per second (primary rays that were generated and tested + reflection and shadow rays
+that were traced); the count of rays the REFERENCE traces for the same frames is reported beside it
+(`reference_rays`), taken from an extra frame with full ray statistics after the timed region.
 
 Prints ONE JSON line on rank 0.
 """
@@ -21,22 +25,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-FLOPS_PER_TEST = 69            # reference triangle test with ray-independent terms hoisted
-PEAK_FP32_TFLOPS = 157.3       # MI355X vector FP32 (256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz)
+FLOPS_PER_TEST = 69            # the reference's triangle test with ray-independent terms hoisted (algorithmic count)
+PEAK_FP32_TFLOPS = 157.3       # MI355X vector FP32, packed (256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz)
+PEAK_FP64_TFLOPS = 78.6        # MI355X vector FP64 (256 CU x 4 SIMD x 32 FLOP/clk x 2.4 GHz)
 PEAK_HBM_GBPS = 8000.0         # MI355X HBM3E
-SHADE_BYTES_PER_HIT = 64       # algorithmic HBM bytes of the shading kernels per shaded hit (see the roofline object)
-PEAK_FP64_TFLOPS = 78.6        # MI355X vector FP64 (256 CU x 4 SIMD x 32 FLOP/clk x 2.4 GHz; v_fma_f64 measured at 73 TFLOP/s)
-
-
-def shade_flops_per_hit(n_lights, n_sphere_like):
-    """FP64 operations of calculateLighting (RayTracingFunctions.swift:182-271) for one triangle hit with a
-    material in a scene whose other objects are `n_sphere_like` material-less bounding spheres (form B);
-    +, -, *, /, sqrt and pow count 1 each, a normalize is 9 (dot 5, sqrt, 3 divisions):
-    hit point 6, surfaceToCamera 12, reflection direction 12, the reflection ray's sphere tests
-    22 each + 13 for the hit it finds, the unlit reflected hit's light loop 26 per light,
-    and per light of the primary hit 57 (direction 12, n.l 5, diffuse 9, reflection of the light 16,
-    r.v 5, pow 1, specular 9)."""
-    return 6 + 12 + 12 + 22 * n_sphere_like + 13 + 26 * n_lights + 57 * n_lights
+SIMDS = 1024                   # 256 CUs x 4
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_kernels.json")
 
 CONFIGS = {
     # name: (width, height, subdivision, mesh level, n_lights)
@@ -46,25 +40,79 @@ CONFIGS = {
 }
 
 
+def shade_flops_per_hit(n_lights, inert, n_sphere_like=1):
+    """FP64 operations of calculateLighting (RayTracingFunctions.swift:182-271) for one triangle hit with a material
+    in a scene whose other objects are `n_sphere_like` material-less bounding spheres (form B); +, -, *, /, sqrt and
+    pow count 1 each, a normalize is 9 (dot 5, sqrt, 3 divisions).
+    Always: hit point 6, ambient 3, surfaceToCamera 12, and per light 57 (direction 12, n.l 5, diffuse 9, reflection of
+    the light 16, r.v 5, pow 1, specular 9).
+    Only when the secondary rays are traced (inert = False; the reference always does): reflection direction 12, the
+    reflection ray's sphere tests 22 each + 13 for the hit it finds, the unlit reflected hit's light loop 26 per light."""
+    always = 6 + 3 + 12 + 57 * n_lights
+    secondary = 12 + 22 * n_sphere_like + 13 + 26 * n_lights
+    return always if inert else always + secondary
+
+
+def pmc_kernel(config, kernel):
+    """Counters of `kernel` per launch from the committed PMC passes of this configuration (bench.py itself cannot
+    collect PMC counters); None if there are none."""
+    try:
+        d = json.load(open(PMC_FILE))
+    except OSError:
+        return None
+    return d.get(config, {}).get(kernel)
+
+
+def pmc_fractions(k):
+    """What the hardware executed, from the counters of one launch (formulas spelled out in the result):
+    executed FP64 (or FP32) flops per second against the peak, and the share of cycles the VALU issued."""
+    if not k:
+        return None
+    ms = k["avg_launch_ms"]
+    out = {"source": k.get("source"), "avg_launch_ms_profiled": ms}
+    f64 = 64 * (k.get("SQ_INSTS_VALU_ADD_F64", 0) + k.get("SQ_INSTS_VALU_MUL_F64", 0) + 2 * k.get("SQ_INSTS_VALU_FMA_F64", 0)
+                + k.get("SQ_INSTS_VALU_TRANS_F64", 0))
+    f32 = 64 * (k.get("SQ_INSTS_VALU_ADD_F32", 0) + k.get("SQ_INSTS_VALU_MUL_F32", 0) + 2 * k.get("SQ_INSTS_VALU_FMA_F32", 0))
+    if f64:
+        out["executed_fp64_tflops"] = round(f64 / (ms * 1e-3) / 1e12, 3)
+        out["executed_fp64_frac_of_peak"] = round(f64 / (ms * 1e-3) / 1e12 / PEAK_FP64_TFLOPS, 4)
+        out["executed_fp64_formula"] = "64 lanes x (ADD_F64 + MUL_F64 + 2 FMA_F64 + TRANS_F64 wave-instructions) / launch time / 78.6 TFLOP/s"
+    if f32:
+        out["executed_fp32_tflops_if_unpacked"] = round(f32 / (ms * 1e-3) / 1e12, 3)
+        out["executed_fp32_frac_of_peak_if_unpacked"] = round(f32 / (ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, 4)
+        out["executed_fp32_formula"] = ("64 lanes x (ADD_F32 + MUL_F32 + 2 FMA_F32 wave-instructions) / launch time / 157.3 TFLOP/s; the "
+                                        "counters tally a packed v_pk_* instruction once, so a loop of packed instructions executes up "
+                                        "to twice this")
+    if k.get("SQ_ACTIVE_INST_VALU") and k.get("GRBM_GUI_ACTIVE"):
+        out["valu_issue_frac"] = round(k["SQ_ACTIVE_INST_VALU"] * 4 / (k["GRBM_GUI_ACTIVE"] / 8 * SIMDS), 4)
+        out["valu_issue_formula"] = "SQ_ACTIVE_INST_VALU x 4 cycles / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)"
+    if k.get("hbm_bytes_per_launch"):
+        out["hbm_bytes_per_launch"] = k["hbm_bytes_per_launch"]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C3", choices=sorted(CONFIGS))
     ap.add_argument("--form", default="B", choices=["B", "T"])
     ap.add_argument("--search", default="tree", choices=["tree", "scan"],
                     help="triangle search of the timed region: the cone tree (default) or the list scan")
-    ap.add_argument("--no-scan-leg", action="store_true",
-                    help="skip the extra list-scan frames that measure BASELINE's tests/s figure (1 GPU only)")
-    ap.add_argument("--orbit", action="store_true", help="config 5: move the camera every step")
+    ap.add_argument("--static-camera", action="store_true", help="hold the camera still (default: it moves every step)")
+    ap.add_argument("--orbit", action="store_true", help="(default now) move the camera every step")
     ap.add_argument("--ray-stats", action="store_true",
                     help="keep the reference's ray statistics in the timed frames (every ray the reference would trace is "
                          "counted, which costs the tracing of rays that cannot change a pixel)")
+    ap.add_argument("--no-aux", action="store_true",
+                    help="skip the legs after the timed region (reference ray counts, static camera, list scan, form T)")
+    ap.add_argument("--no-scan-leg", action="store_true", help="skip the list-scan leg only")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-threads", type=int, default=16)
-    ap.add_argument("--verify", action="store_true",
-                    help="after timing, rank 0 re-renders the last frame alone and compares it byte for byte")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="N > 1: do not re-render the last frame on rank 0 alone to compare it byte for byte")
+    ap.add_argument("--verify", action="store_true", help="(default for N > 1)")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="multi-rank logic check on a box with ONE GPU: all ranks render on device 0 and the "
                          "collectives run over gloo on host tensors (not a performance mode)")
@@ -74,7 +122,7 @@ def main():
     import torch.distributed as dist
 
     import raytracer_amd as rt
-    from raytracer_amd import scenes, sharding
+    from raytracer_amd import _abi, scenes, sharding
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -117,71 +165,65 @@ def main():
     if world > 1:
         data = sharding.broadcast_scene(data, 0, device=comm_dev)  # RCCL byte broadcast, once
     scene = rt.Scene(data, device=local_rank)
-    from raytracer_amd import _abi
     search = _abi.RTMI_SEARCH_CONE_TREE if args.search == "tree" else _abi.RTMI_SEARCH_LIST_SCAN
-    # timed frames ask for pixels only (RTMI_FLAG_NO_RAY_STATISTICS): rays whose outcome cannot change a pixel are then
-    # neither traced nor counted; --ray-stats keeps the reference's full ray statistics inside the timed region
     flags = 0 if args.ray_stats else _abi.RTMI_FLAG_NO_RAY_STATISTICS
     params = scenes.make_params(W, H, sub, search=search, flags=flags)
     my_params = sharding.tile_params(params, rank, world) if world > 1 else params
     composer = sharding.TileComposer(W, H, rank, world, comm_dev)
     staging = [torch.zeros((H, W, 4), dtype=torch.uint8, device=dev) for _ in range(2)] if args.rehearse_gloo else None
     torch.cuda.synchronize()
+    moving = not args.static_camera
 
     def camera_for(step):
-        if args.orbit:
+        if moving:
             return scenes.make_camera(**scenes.orbit_camera(step % 64))
         return scenes.make_camera(**scenes.MESH_CAMERA)
 
-    totals = {"rays": 0, "refl": 0, "shadow": 0, "elided": 0, "tests": 0, "tests_primary": 0, "ms_primary": 0.0, "launches": 0, "ms_total": 0.0,
-              "exact": 0, "samples": 0, "hits": 0, "ms_shade": 0.0, "node_tests": 0, "candidates": 0}
+    keys = ("samples", "primary_rays_traced", "rays_reflection", "rays_shadow", "shadow_rays_elided", "tri_tests",
+            "tri_tests_primary_kernel", "ms_primary_kernel", "ms_total", "tri_search_launches", "tri_exact_tests", "primary_hits",
+            "ms_shade", "node_tests", "tri_candidates")
+    totals = {k: 0 for k in keys}
+    host = {"enqueue_s": 0.0, "wait_s": 0.0, "compose_s": 0.0}
 
     # With more than one rank a frame is short (1/N of the work) and the gaps between frames start to show: each
-    # rank then keeps TWO frames in flight, on two scene objects with a stream and work buffers of their own
-    # (measured on the 1/8 share of this workload: 0.524 -> 0.493 ms per frame).  Frame i is enqueued before
-    # frame i-1 is waited for; the gather of frame i-1 then overlaps the rendering of frame i.
+    # rank then keeps TWO frames in flight, on two scene objects with a stream and work buffers of their own.
+    # Frame i is enqueued before frame i-1 is waited for; the gather of frame i-1 then overlaps the rendering of frame i.
     scenes_in_flight = [scene] + ([rt.Scene(data, device=local_rank)] if world > 1 else [])
     depth = len(scenes_in_flight)
     in_flight = []  # (scene, slot, record) of frames enqueued and not yet waited for
 
-    def account(cnt):
-        totals["rays"] += cnt["samples"] + cnt["rays_reflection"] + cnt["rays_shadow"]
-        totals["samples"] += cnt["samples"]
-        totals["refl"] += cnt["rays_reflection"]
-        totals["shadow"] += cnt["rays_shadow"]
-        totals["elided"] += cnt["shadow_rays_elided"]
-        totals["tests"] += cnt["tri_tests"]
-        totals["tests_primary"] += cnt["tri_tests_primary_kernel"]
-        totals["ms_primary"] += cnt["ms_primary_kernel"]
-        totals["ms_total"] += cnt["ms_total"]
-        totals["launches"] += cnt["tri_search_launches"]
-        totals["exact"] += cnt["tri_exact_tests"]
-        totals["hits"] += cnt["primary_hits"]
-        totals["ms_shade"] += cnt["ms_shade"]
-        totals["node_tests"] += cnt["node_tests"]
-        totals["candidates"] += cnt["tri_candidates"]
-
     def retire_oldest():
         sc_, slot_, record_ = in_flight.pop(0)
+        t0 = time.perf_counter()
         cnt = sc_.render_end()
+        t1 = time.perf_counter()
         if args.rehearse_gloo:
             composer.frames[slot_].copy_(staging[slot_])
         composer.compose(slot_)  # travels to rank 0 while the next frame renders
+        t2 = time.perf_counter()
         if record_:
-            account(cnt)
+            for k in keys:
+                totals[k] += cnt[k]
+            host["wait_s"] += t1 - t0
+            host["compose_s"] += t2 - t1
 
     def step(i, record):
-        # Frames alternate between two buffers.  Frame i reuses the buffer of frame i-2: that frame is waited
-        # for and its gather enqueued (retire_oldest), and the gather's read of the buffer must have happened
-        # (wait_slot), before frame i is enqueued.  Frame i-1 keeps the GPU busy meanwhile.
+        # Frames alternate between two buffers.  Frame i reuses the buffer of frame i-2: that frame has been waited
+        # for and its gather enqueued (retire_oldest); the scene's stream is ordered behind that gather's last touch of
+        # the buffer with an event (no host wait), and frame i-1 keeps the GPU busy meanwhile.
         slot = i & 1
         if len(in_flight) == depth:
             retire_oldest()
-        composer.wait_slot(slot)
+        t0 = time.perf_counter()
         sc_ = scenes_in_flight[i % depth]
+        ev = composer.slot_event(slot)
+        if ev is not None:
+            sc_.wait_event(ev.cuda_event)
         target = staging[slot] if args.rehearse_gloo else composer.frames[slot]
         sc_.render_begin(camera_for(i), my_params, target.data_ptr())   # enqueue frame i, do not wait
         in_flight.append((sc_, slot, record))
+        if record:
+            host["enqueue_s"] += time.perf_counter() - t0
 
     def flush():
         while in_flight:
@@ -206,7 +248,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     verified = None
-    if args.verify and rank == 0:
+    if world > 1 and not args.no_verify and rank == 0:
         alone = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
         torch.cuda.synchronize()
         scene.render_device(camera_for(args.warmup + args.steps - 1), params, alone.data_ptr())
@@ -214,107 +256,100 @@ def main():
         verified = bool((alone.cpu() == last.cpu()).all())
         assert verified, "the composed multi-rank frame differs from the single-GPU frame"
 
-    agg = torch.tensor([float(totals["rays"]), float(totals["tests"]), elapsed], dtype=torch.float64, device=comm_dev)
+    traced = totals["primary_rays_traced"] + totals["rays_reflection"] + totals["rays_shadow"] - totals["shadow_rays_elided"]
+    mine = [float(traced), float(totals["tri_tests"]), elapsed, totals["ms_total"] / args.steps,
+            host["enqueue_s"] / args.steps * 1e3, host["wait_s"] / args.steps * 1e3, host["compose_s"] / args.steps * 1e3]
+    agg = torch.tensor(mine, dtype=torch.float64, device=comm_dev)
     if world > 1:
-        sums = agg.clone()
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
-        mx = agg.clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        total_rays, total_tests, elapsed_max = sums[0].item(), sums[1].item(), mx[2].item()
+        every = [torch.zeros_like(agg) for _ in range(world)]
+        dist.all_gather(every, agg)
+        per_rank = [e.cpu().tolist() for e in every]
     else:
-        total_rays, total_tests, elapsed_max = agg[0].item(), agg[1].item(), elapsed
+        per_rank = [mine]
+    total_traced = sum(r[0] for r in per_rank)
+    total_tests = sum(r[1] for r in per_rank)
+    elapsed_max = max(r[2] for r in per_rank)
 
-    scan_leg = None
-    if rank == 0 and world == 1 and args.search == "tree" and not args.no_scan_leg:
-        scan_leg = list_scan_leg(scene, camera_for(args.warmup), params, composer.frames[0], min(3, max(1, args.steps)), args.config)
+    aux = {}
+    if rank == 0 and world == 1 and not args.no_aux:
+        aux = aux_legs(rt, scene, data, params, composer.frames[0], camera_for, args, level, n_lights)
 
     if rank == 0:
-        mrays = total_rays / elapsed_max / 1e6
-        tests_per_s = total_tests / elapsed_max
-        launches = max(totals["launches"], 1)
-        if args.search == "scan":
-            avg_ms = totals["ms_primary"] / launches
-            roofline = scan_roofline(totals["tests_primary"] / launches, avg_ms, args.config)
-        else:
-            # the dominant kernel of the timed region is the shading of the decided hits (FP64)
-            flops_hit = shade_flops_per_hit(n_lights, 1 if args.form == "B" else 0)
-            ms_shade = totals["ms_shade"] / args.steps
-            hits = totals["hits"] / args.steps
-            achieved = hits * flops_hit / (ms_shade * 1e-3) / 1e12 if ms_shade > 0 else 0.0
-            roofline = {
-                "bound": "valu_fp64",
-                "kernel": "k_shade_candidates" if args.form == "B" else "k_shade",
-                "achieved": round(achieved, 3),
-                "peak": PEAK_FP64_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_FP64_TFLOPS, 4),
-                "traffic": traffic_from_profile(args.config, "k_shade_candidates"),
-                "traffic_unit": "bytes of HBM traffic per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes; profiles/)",
-                "flops_per_hit_algorithmic": flops_hit,
-                "hits_per_launch": hits,
-                "avg_launch_ms": round(ms_shade, 4),
-                # the same launch against the HBM roofline: per shaded hit the kernel reads its candidate entry (8 B),
-                # the ray's best list position (4 B) and direction (24 B) and writes hit id (4 B) and colour (24 B);
-                # triangles, planes, materials and lights are a few hundred KB and stay in cache
-                "hbm_view": {"algorithmic_bytes_per_hit": SHADE_BYTES_PER_HIT,
-                             "achieved": round(hits * SHADE_BYTES_PER_HIT / (ms_shade * 1e-3) / 1e9, 1) if ms_shade > 0 else 0.0,
-                             "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                             "frac": round(hits * SHADE_BYTES_PER_HIT / (ms_shade * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4) if ms_shade > 0 else 0.0},
-                "note": "achieved = shaded hits per launch x the FP64 operations of calculateLighting per hit (division, sqrt, "
-                        "pow counted as 1) / launch time (HIP events on the library's stream).  An IEEE FP64 division costs "
-                        "about 13 instructions on this ISA and a sqrt about 20, and the reference's arithmetic (3 divisions "
-                        "per normalize) is kept operation for operation, so the kernel executes several instructions "
-                        "per counted operation (about 2.6 on this kernel: 820 VALU instructions per 64 shaded hits, profiles/).",
-            }
+        steps = args.steps
+        ms_step = elapsed_max / steps * 1e3
+        ref = aux.get("reference_counts")
+        inert = args.form == "B" and not args.ray_stats and args.search == "tree"
+        roofline = shade_roofline(args, totals, steps, n_lights, inert) if args.search == "tree" else \
+            scan_roofline(totals["tri_tests_primary_kernel"] / max(totals["tri_search_launches"], 1),
+                          totals["ms_primary_kernel"] / max(totals["tri_search_launches"], 1), args.config)
         out = {
             "metric": "Mrays/s + ray-tri tests/s (% FP32 peak), pig OBJ 4K 16spp, 1/2/4/8 GPU",
-            "value": round(mrays, 3),
+            "value": round(total_traced / elapsed_max / 1e6, 3),
             "unit": "Mrays/s",
+            "value_note": "rays actually traced per second: primary rays that were generated and tested with the reference's "
+                          "arithmetic, plus the reflection and shadow rays that were traced.  Samples cleared beforehand by a "
+                          "conservative test and rays whose outcome cannot change a pixel are not counted.",
             "n_gpus": world,
-            "steps": args.steps,
+            "steps": steps,
             "warmup": args.warmup,
-            "ms_per_step": round(elapsed_max / args.steps * 1e3, 4),
+            "ms_per_step": round(ms_step, 4),
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32 filter + f64 decision",
+            "dtype": "f64",
+            "dtype_note": "every decision (ray generation, sphere and triangle tests, shading) is FP64 in the reference's operation "
+                          "order; FP32 is used only by conservative filters that nominate (ray, triangle) pairs",
             "data": "synthetic",
             "config": {
                 "workload": f"{args.config}: pig mesh [{mesh_note}; default = displaced icosphere level {level}], "
                             f"{len(data.triangles)} triangles, {W}x{H}, {scene_spp(sub)} spp, {n_lights} lights, "
                             f"form {args.form} ({'bounded by Sphere(boundingObjects:)' if args.form == 'B' else 'top-level triangles'}), "
-                            "list-order hit policy" + (", orbiting camera" if args.orbit else ""),
+                            "list-order hit policy, " + ("camera moving every frame (orbit of config 5)" if moving else "camera held still")
+                            + (", full ray statistics" if args.ray_stats else ", pixels only (no ray statistics)"),
                 "mesh": mesh_note,
                 "search": "cone tree (per-frame cone hierarchy; every hit of a ray is found, the lowest list position wins)"
                           if args.search == "tree" else "list scan (every front-facing triangle in list order until the ray's first hit)",
                 "tiles": "32x32 cyclic over ranks, own pixels gathered on rank 0" if world > 1 else "single GPU, whole frame",
             },
             "verified_against_single_gpu_frame": verified,
-            "rays_per_step": int(total_rays / args.steps),
-            "rays_per_step_rank0": {"primary": totals["samples"] // args.steps, "reflection": totals["refl"] // args.steps,
-                                    "shadow": totals["shadow"] // args.steps,
-                                    "shadow_elided": totals["elided"] // args.steps,
-                                    "note": "ray counts follow the reference (the oracle's counters); 'shadow_elided' of the "
-                                            "shadow rays start at hits on material-less objects and are not traced because "
-                                            "their outcome cannot change the pixel"},
-            "tests_per_s": tests_per_s,
+            "traced_rays_per_step": int(total_traced / steps),
+            "traced_rays_per_step_rank0": {"primary": totals["primary_rays_traced"] // steps,
+                                           "primary_cleared_untraced": (totals["samples"] - totals["primary_rays_traced"]) // steps,
+                                           "reflection": totals["rays_reflection"] // steps,
+                                           "shadow": (totals["rays_shadow"] - totals["shadow_rays_elided"]) // steps},
+            "reference_rays": None if not ref else {
+                "per_step": ref["rays"],
+                "mrays_per_s_equivalent": round(ref["rays"] / (ms_step * 1e-3) / 1e6, 1),
+                "breakdown": ref["breakdown"],
+                "note": "rays the REFERENCE traces for one such frame (primary + reflection + shadow; equal to the oracle's "
+                        "counters), from an extra frame with full ray statistics after the timed region, divided by the timed "
+                        "frame time.  Most of them are never traced here: primary rays that a conservative test clears, and "
+                        "on this scene every reflection and shadow ray (nothing they could hit changes a pixel).",
+                "ms_per_step_with_full_ray_statistics": ref["ms"]},
+            "tests_per_s": total_tests / elapsed_max,
             "tests_note": "(ray, triangle) pairs actually evaluated by a kernel lane per second over the timed region; pairs "
                           "skipped by the origin-side cull, the cone tree or a ray's early exit are not counted",
-            "tests_per_s_frac_of_fp32_roofline": tests_per_s * FLOPS_PER_TEST / (PEAK_FP32_TFLOPS * 1e12 * world),
-            "search_rank0_per_step": {"ms_tri_search": round(totals["ms_primary"] / args.steps, 4),
-                                      "ms_shade": round(totals["ms_shade"] / args.steps, 4),
-                                      "tri_tests": totals["tests_primary"] // args.steps,
-                                      "node_tests": totals["node_tests"] // args.steps,
-                                      "candidates": totals["candidates"] // args.steps,
-                                      "fp64_decisions": totals["exact"] // args.steps,
-                                      "primary_hits": totals["hits"] // args.steps},
-            "device_ms_per_step_rank0": round(totals["ms_total"] / args.steps, 4),
+            "algorithmic_69flop_equiv_tflops": round(total_tests / elapsed_max * FLOPS_PER_TEST / 1e12, 3),
+            "algorithmic_69flop_equiv_note": "evaluated pairs per second x the 69 flops of the reference's triangle test: NOT an "
+                                            "executed-flop rate (the filter cascade executes about 7 FP32 flops per pair)",
+            "search_rank0_per_step": {"ms_tri_search": round(totals["ms_primary_kernel"] / steps, 4),
+                                      "ms_shade": round(totals["ms_shade"] / steps, 4),
+                                      "tri_tests": totals["tri_tests_primary_kernel"] // steps,
+                                      "node_tests": totals["node_tests"] // steps,
+                                      "candidates": totals["tri_candidates"] // steps,
+                                      "fp64_decisions": totals["tri_exact_tests"] // steps,
+                                      "primary_hits": totals["primary_hits"] // steps},
+            "device_ms_per_step_rank0": round(totals["ms_total"] / steps, 4),
+            "per_rank": [{"rank": r, "device_ms_per_step": round(v[3], 4), "wall_ms_per_step": round(v[2] / steps * 1e3, 4),
+                          "host_enqueue_ms": round(v[4], 4), "host_wait_ms": round(v[5], 4), "host_compose_enqueue_ms": round(v[6], 4)}
+                         for r, v in enumerate(per_rank)],
             "roofline": roofline,
         }
-        if scan_leg is not None:
-            out["list_scan"] = scan_leg
+        for k in ("static_camera", "list_scan", "form_T"):
+            if k in aux:
+                out[k] = aux[k]
         if not args.no_cpu and world == 1:
-            out["cpu_baseline"] = cpu_baseline(data, params, args.cpu_threads)
+            out["cpu_baseline"] = cpu_baseline(data, params, args.cpu_threads, args.config, moving)
         print(json.dumps(out), flush=True)
 
     for sc_ in scenes_in_flight:
@@ -323,69 +358,119 @@ def main():
         dist.destroy_process_group()
 
 
-def traffic_from_profile(config, kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC profile of this configuration
-    (bench.py itself cannot collect PMC counters); None if there is none for `config`."""
-    name = {"k_search_primary": "r01_pmc_search_kernel.json", "k_shade_candidates": "r01_pmc_shade_kernel.json"}[kernel]
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", name)))
-    except OSError:
-        return None
-    return d.get("hbm_bytes_per_launch") if d.get("config") == config else None
-
-
-def scan_roofline(tests_per_launch, avg_ms, config):
-    """BASELINE's figure for the list-scan kernel: evaluated pairs x 69 algorithmic flops / launch time."""
-    achieved = tests_per_launch * FLOPS_PER_TEST / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+def shade_roofline(args, totals, steps, n_lights, inert):
+    """The dominant kernel of the timed region: the shading of the decided hits (FP64 VALU)."""
+    flops_hit = shade_flops_per_hit(n_lights, inert, 1 if args.form == "B" else 0)
+    flops_hit_ref = shade_flops_per_hit(n_lights, False, 1 if args.form == "B" else 0)
+    ms_shade = totals["ms_shade"] / steps
+    hits = totals["primary_hits"] / steps
+    achieved = hits * flops_hit / (ms_shade * 1e-3) / 1e12 if ms_shade > 0 else 0.0
+    kernel = "k_shade_candidates<false, true>" if inert else ("k_shade_candidates<false, false>" if args.form == "B" else "k_shade<true>")
+    bytes_hit = 64  # candidate entry 8 + best position 4 + direction 24 read; hit id 4 + colour 24 written
+    pmc = pmc_fractions(pmc_kernel(args.config, kernel))
     return {
-        "bound": "valu_fp32",
-        "kernel": "k_search_primary",
+        "bound": "valu_fp64",
+        "kernel": kernel,
         "achieved": round(achieved, 3),
-        "peak": PEAK_FP32_TFLOPS,
+        "peak": PEAK_FP64_TFLOPS,
         "unit": "TFLOP/s",
-        "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
-        "traffic": traffic_from_profile(config, "k_search_primary"),
-        "traffic_unit": "bytes of HBM traffic per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, "
-                        "separate passes; profiles/r01_pmc_search_kernel.json)",
-        "flops_per_test_algorithmic": FLOPS_PER_TEST,
-        "tests_per_launch": tests_per_launch,
-        "avg_launch_ms": round(avg_ms, 4),
-        "executed_fp32_flops_per_test": 7,
-        "note": "achieved = evaluated (ray, triangle) pairs per launch x 69 algorithmic flops / launch time "
-                "(HIP events on the library's stream).  The kernel decides most pairs with a conservative "
-                "3-FMA cone test (about 7 executed FP32 flops per pair incl. the max), the rest with a 9-FMA "
-                "edge test and an FP64 reference-order test, so frac exceeds 1 by construction; the VALU "
-                "is 88% busy during the launch (SQ_ACTIVE_INST_VALU, profiles/).",
+        "frac": round(achieved / PEAK_FP64_TFLOPS, 4),
+        "traffic": pmc.get("hbm_bytes_per_launch") if pmc else None,
+        "traffic_unit": "bytes of HBM traffic per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes; "
+                        "profiles/r02_pmc_kernels.json)",
+        "flops_per_hit_algorithmic": flops_hit,
+        "flops_per_hit_as_the_reference_evaluates_it": flops_hit_ref,
+        "hits_per_launch": hits,
+        "avg_launch_ms": round(ms_shade, 4),
+        "executed": pmc,
+        "hbm_view": {"algorithmic_bytes_per_hit": bytes_hit,
+                     "achieved": round(hits * bytes_hit / (ms_shade * 1e-3) / 1e9, 1) if ms_shade > 0 else 0.0,
+                     "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                     "frac": round(hits * bytes_hit / (ms_shade * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4) if ms_shade > 0 else 0.0},
+        "note": "achieved = shaded hits per launch x the FP64 operations of calculateLighting that the launch has to perform per "
+                "hit (division, sqrt, pow counted as 1; with pixels only on this scene the secondary rays' operations are not "
+                "performed and not counted) / launch time (HIP events on the library's stream).  The reference's arithmetic is "
+                "kept bit for bit, and IEEE FP64 division and square root are instruction sequences on this ISA: measured "
+                "(profiles/r02_ubench_fp64.txt) a division occupies a SIMD for 65 cycles per wave, a square root for 90, a "
+                "multiply-add for 5; the 7 normalizations of a hit alone are 7 x 216 cycles.  `executed` holds what the "
+                "hardware did according to the PMC counters.",
     }
 
 
-def list_scan_leg(scene, cam, params, frame, steps, config):
-    """The same frame with RTMI_SEARCH_LIST_SCAN, after the timed region: the brute-force figure BASELINE's
-    metric names (ray-triangle tests/s against the FP32 peak) for the kernel that performs it."""
+def scan_roofline(tests_per_launch, avg_ms, config):
+    """The list-scan kernel: evaluated pairs and what the hardware executed for them."""
+    pmc = pmc_fractions(pmc_kernel(config, "k_search_primary<4>"))
+    r = {
+        "bound": "valu_fp32",
+        "kernel": "k_search_primary<4>",
+        "unit": "TFLOP/s",
+        "peak": PEAK_FP32_TFLOPS,
+        "tests_per_launch": tests_per_launch,
+        "avg_launch_ms": round(avg_ms, 4),
+        "algorithmic_69flop_equiv_tflops": round(tests_per_launch * FLOPS_PER_TEST / (avg_ms * 1e-3) / 1e12, 3) if avg_ms > 0 else 0.0,
+        "executed": pmc,
+        "traffic": pmc.get("hbm_bytes_per_launch") if pmc else None,
+        "note": "The kernel decides most pairs with a conservative 3-FMA cone test (about 7 executed FP32 flops per pair incl. "
+                "the max), the rest with a 9-FMA edge test and an FP64 reference-order test.  The roofline fraction is the "
+                "EXECUTED FP32 rate from the PMC counters (`executed`), not pairs x 69.",
+    }
+    if pmc and "executed_fp32_frac_of_peak_if_unpacked" in pmc:
+        r["achieved"] = pmc["executed_fp32_tflops_if_unpacked"]
+        r["frac"] = pmc["executed_fp32_frac_of_peak_if_unpacked"]
+    else:
+        r["achieved"] = None
+        r["frac"] = None
+    return r
+
+
+def aux_legs(rt, scene, data, params, frame, camera_for, args, level, n_lights):
+    """Extra frames after the timed region (1 GPU): the reference's ray counts, the still camera, the list scan, form T."""
     import copy
     import torch
-    from raytracer_amd import _abi
+    from raytracer_amd import _abi, scenes
+    out = {}
+    cam = camera_for(args.warmup)
+
+    def run(sc, p, cameras):
+        sc.render_device(cameras[0], p, frame.data_ptr())  # warm-up: operands for this search / camera
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        cnts = [sc.render_device(c, p, frame.data_ptr()) for c in cameras]
+        return (time.perf_counter() - t0) / len(cameras) * 1e3, cnts
+
+    # full ray statistics: what the reference traces for this frame
     p = copy.copy(params)
-    p.search = _abi.RTMI_SEARCH_LIST_SCAN
-    scene.render_device(cam, p, frame.data_ptr())  # warm-up: packs the list-scan operands
-    tests = ms = ms_total = rays = 0.0
-    launches = 0
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        c = scene.render_device(cam, p, frame.data_ptr())
-        tests += c["tri_tests_primary_kernel"]
-        ms += c["ms_primary_kernel"]
-        ms_total += c["ms_total"]
-        launches += c["tri_search_launches"]
-        rays += c["samples"] + c["rays_reflection"] + c["rays_shadow"]
-    dt = time.perf_counter() - t0
-    launches = max(launches, 1)
-    r = scan_roofline(tests / launches, ms / launches, config)
-    r.update({"steps": steps, "ms_per_step": round(dt / steps * 1e3, 4), "mrays_per_s": round(rays / dt / 1e6, 3),
-              "tests_per_s": tests / dt,
-              "tests_per_s_frac_of_fp32_roofline": tests / dt * FLOPS_PER_TEST / (PEAK_FP32_TFLOPS * 1e12)})
-    return r
+    p.flags = 0
+    ms, cnts = run(scene, p, [cam] * 3)
+    c = cnts[-1]
+    out["reference_counts"] = {"rays": c["samples"] + c["rays_reflection"] + c["rays_shadow"], "ms": round(ms, 4),
+                               "breakdown": {"primary": c["samples"], "reflection": c["rays_reflection"], "shadow": c["rays_shadow"],
+                                             "of_shadow_not_traced_even_with_statistics": c["shadow_rays_elided"]}}
+    # the camera held still: camera-dependent preparation (sample tables, cone tree) is reused
+    ms, _ = run(scene, params, [scenes.make_camera(**scenes.MESH_CAMERA)] * 5)
+    out["static_camera"] = {"ms_per_step": round(ms, 4), "steps": 5}
+    if args.search == "tree" and not args.no_scan_leg:
+        p = copy.copy(params)
+        p.search = _abi.RTMI_SEARCH_LIST_SCAN
+        ms, cnts = run(scene, p, [cam] * 3)
+        launches = max(sum(c["tri_search_launches"] for c in cnts), 1)
+        r = scan_roofline(sum(c["tri_tests_primary_kernel"] for c in cnts) / launches, sum(c["ms_primary_kernel"] for c in cnts) / launches,
+                          args.config)
+        r.update({"steps": 3, "ms_per_step": round(ms, 4),
+                  "tests_per_s": sum(c["tri_tests_primary_kernel"] for c in cnts) / (ms * 3e-3)})
+        out["list_scan"] = r
+    if args.form == "B" and args.config != "C4":
+        # the same mesh listed at top level: the only form in which reflection and shadow rays do triangle work
+        dT = scenes.mesh_scene(level, "T", n_lights)
+        sT = rt.Scene(dT, device=scene.device)
+        ms, cnts = run(sT, params, [cam] * 2)
+        c = cnts[-1]
+        traced = c["primary_rays_traced"] + c["rays_reflection"] + c["rays_shadow"] - c["shadow_rays_elided"]
+        out["form_T"] = {"ms_per_step": round(ms, 4), "steps": 2, "traced_rays_per_step": traced,
+                         "mrays_per_s": round(traced / (ms * 1e-3) / 1e6, 1), "tri_tests_per_step": c["tri_tests"],
+                         "ms_shade": round(c["ms_shade"], 4)}
+        sT.close()
+    return out
 
 
 def scene_spp(sub):
@@ -404,16 +489,16 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(data, params, threads):
-    """The CPU oracle (FP64 restatement of the reference) on a bounded sample of the same workload:
-    a centre window of the same frame, same scene, same spp."""
+def cpu_baseline(data, params, threads, config, moving):
+    """The CPU oracle (FP64 restatement of the reference) on a bounded sample of the same workload -- a centre window of
+    the same frame, same scene, same spp -- extrapolated to the whole frame by ray-triangle test count (the oracle's
+    full-frame counters are in tests/golden/fullframe_hashes.json)."""
     import oracle
     from raytracer_amd import scenes
     W, H = params.width, params.height
     ww, wh = min(W - 1, 1024), min(H - 1, 512)
     x0, y0 = (W - 1 - ww) // 2, (H - 1 - wh) // 2
-    win = (x0, y0, x0 + ww, y0 + wh)
-    p = scenes.make_params(W, H, params.pixel_subdivision, tuple(params.ambient), window=win)
+    p = scenes.make_params(W, H, params.pixel_subdivision, tuple(params.ambient), window=(x0, y0, x0 + ww, y0 + wh))
     cam = scenes.make_camera(**scenes.MESH_CAMERA)
     t0 = time.perf_counter()
     _, _, cnt = oracle.render(data, cam, p, want_hit_ids=False, threads=threads)
@@ -426,22 +511,32 @@ def cpu_baseline(data, params, threads):
     t1 = time.perf_counter()
     _, _, c1 = oracle.render(data, cam, p1, want_hit_ids=False, threads=1)
     d1 = time.perf_counter() - t1
-    rays1 = c1["samples"] + c1["rays_reflection"] + c1["rays_shadow"]
-    return {
+    out = {
         "value": round(rays / dt / 1e6, 4),
         "unit": "Mrays/s",
         "cores": threads,
         "cpu_model": cpu_model(),
         "kind": "port",
-        "sample": f"centre window {ww}x{wh} px of the same frame ({cnt['samples']} primary rays, "
-                  f"{cnt['tri_tests']} ray-triangle tests, {dt:.1f} s); the window lies inside the mesh silhouette, "
-                  "so its rays are costlier than the frame average",
+        "sample": f"centre window {ww}x{wh} px of the same frame, still camera ({cnt['samples']} primary rays, "
+                  f"{cnt['tri_tests']} ray-triangle tests, {dt:.1f} s); rays are the reference's count for the window; the window "
+                  "lies inside the mesh silhouette, so its rays are costlier than the frame average",
         "tests_per_s": cnt["tri_tests"] / dt,
         "seconds": round(dt, 2),
-        "single_thread": {"value": round(rays1 / d1 / 1e6, 4), "unit": "Mrays/s", "cores": 1,
-                          "sample": f"centre window {sw}x{sh} px ({c1['samples']} primary rays, {d1:.1f} s)",
+        "single_thread": {"value": round((c1["samples"] + c1["rays_reflection"] + c1["rays_shadow"]) / d1 / 1e6, 4), "unit": "Mrays/s",
+                          "cores": 1, "sample": f"centre window {sw}x{sh} px ({c1['samples']} primary rays, {d1:.1f} s)",
                           "tests_per_s": c1["tri_tests"] / d1},
     }
+    try:
+        full = json.load(open(os.path.join(ROOT, "tests", "golden", "fullframe_hashes.json")))[config]["counters"]
+        frame_s = full["tri_tests"] / (cnt["tri_tests"] / dt)
+        frame_rays = full["samples"] + full["rays_reflection"] + full["rays_shadow"]
+        out["whole_frame_extrapolated"] = {
+            "seconds_per_frame": round(frame_s, 2), "mrays_per_s": round(frame_rays / frame_s / 1e6, 4), "reference_rays_per_frame": frame_rays,
+            "method": f"the oracle's whole-frame count of ray-triangle tests ({full['tri_tests']}, tests/golden/fullframe_hashes.json) "
+                      "divided by the window's tests per second"}
+    except (OSError, KeyError):
+        pass
+    return out
 
 
 if __name__ == "__main__":

@@ -167,6 +167,9 @@ typedef struct {
   int64_t tri_tests_primary_kernel; /* pairs evaluated by the common-origin kernel       */
   double ms_primary_kernel; /* its accumulated launch time                               */
   double ms_shade;          /* device time of the shading launches                       */
+  int64_t primary_rays_traced; /* of samples: those whose ray was generated and tested with the reference's
+                                  arithmetic; the rest were cleared beforehand by a conservative test that shows
+                                  they can hit nothing (whole 8x8 blocks, then single samples)   */
 } rtmi_counters;
 
 typedef struct rtmi_scene rtmi_scene;

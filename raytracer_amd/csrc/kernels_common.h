@@ -49,9 +49,9 @@ struct FrameConst {
   const unsigned char* block_live;
 };
 
-// Work counters are striped over NSLOT cache lines (one 64-byte line per slot) so that the
+// Work counters are striped over NSLOT slots (two 64-byte lines per slot) so that the
 // per-wave atomic adds of a launch do not serialise on one address; the host sums the slots.
-enum { C_REFL = 0, C_SHADOW, C_EXACT, C_HITS, C_TESTS_PRIMARY, C_TESTS_SECONDARY, C_SHADOW_ELIDED, C_NODE_TESTS, C_NCOUNTERS = 8 };
+enum { C_REFL = 0, C_SHADOW, C_EXACT, C_HITS, C_TESTS_PRIMARY, C_TESTS_SECONDARY, C_SHADOW_ELIDED, C_NODE_TESTS, C_PRIMARY_TRACED, C_NCOUNTERS = 16 };
 constexpr int NSLOT = 64;
 
 struct DevCounters {

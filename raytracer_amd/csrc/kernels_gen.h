@@ -58,6 +58,7 @@ k_gen(FrameConst fc, SceneDev sc, const int2* __restrict__ blocks, int nsamples,
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const bool has_top = sc.n_top_tris > 0;
+  unsigned int n_traced = 0;  // samples of this lane whose ray was generated and tested in FP64
   for (int it = 0; it < GEN_ITERS; ++it) {
     const int t = (blockIdx.x * GEN_ITERS + it) * 4 + wv;  // wave-uniform: the 64-sample group of this wave
     const int s = (t << 6) + lane;
@@ -89,6 +90,7 @@ k_gen(FrameConst fc, SceneDev sc, const int2* __restrict__ blocks, int nsamples,
       live = maybe;
     }
     if (live) {
+      ++n_traced;
       d3 d = sample_dir(fc, x, y, kx, ky);
       int obj = first_sphere_like(sc, rtx::ld3(fc.cam), d);
       if (obj >= 0) {
@@ -127,6 +129,7 @@ k_gen(FrameConst fc, SceneDev sc, const int2* __restrict__ blocks, int nsamples,
     int* gq = q == 0 ? q_child : (q == 1 ? q_shade : q_top);
     for (int i = threadIdx.x; i < ln[q]; i += 256) gq[lbase[q] + i] = lq[q][i];
   }
+  wave_count(cnt, C_PRIMARY_TRACED, n_traced);
 }
 
 // After the top-level triangle search: combine the first sphere-like object (hit_id from

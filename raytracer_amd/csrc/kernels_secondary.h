@@ -25,7 +25,7 @@ __device__ inline int first_sphere_like(const SceneDev& sc, d3 o, d3 d) {
   for (int k = 0; k < sc.n_objects; ++k) {
     const rtmi_object& ob = sc.objects[k];
     if (ob.kind == RTMI_SPHERE || ob.kind == RTMI_BOUNDING_SPHERE) {
-      if (rtx::sphere_any(rtx::ld3(ob.center), ob.radius, o, d)) return k;
+      if (rtx::sphere_any_ahead(rtx::ld3(ob.center), ob.radius, o, d)) return k;
     } else if (ob.kind == RTMI_LIGHT) {
       double t;
       d3 P;

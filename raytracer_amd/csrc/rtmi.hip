@@ -1175,6 +1175,7 @@ static int32_t render_finish(rtmi_scene* sc, rtmi_counters* counters) {
     counters->primary_hits = (int64_t)sum[C_HITS];
     counters->shadow_rays_elided = (int64_t)sum[C_SHADOW_ELIDED];
     counters->node_tests = (int64_t)sum[C_NODE_TESTS];
+    counters->primary_rays_traced = (int64_t)sum[C_PRIMARY_TRACED];
     counters->tri_candidates = (int64_t)hc.cand_total;
     counters->ms_total = ms_total;
     counters->ms_tri_search = ms_search;

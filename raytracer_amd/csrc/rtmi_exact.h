@@ -170,10 +170,22 @@ RT_HD bool sphere_any(d3 location, double radius, d3 origin, d3 direction) {
   double a = -dp(direction, center_to_eye);
   double delta = a * a - (len_squared(center_to_eye) - radius_squared);
   if (!(delta >= 0)) return false;
+  double sqrtdelta = sqrt(delta);
   if (delta == 0) return a >= 0.0000001;
-  // t1 = a + sqrt(delta) is at least a (the root is not negative and rounding is monotonic): with a itself
-  // past the threshold -- the sphere's centre lies ahead of the origin -- the answer needs no square root
-  if (a >= 0.0000001) return true;
+  double t1 = a + sqrtdelta, t2 = a - sqrtdelta;
+  return t1 >= 0.0000001 || t2 >= 0.0000001;
+}
+
+// The same answer for callers that can afford a branch (ray generation): t1 = a + sqrt(delta) is at least a
+// (the root is not negative and rounding is monotonic), so with a itself past the threshold -- the sphere's
+// centre lies ahead of the origin -- no square root is needed.
+RT_HD bool sphere_any_ahead(d3 location, double radius, d3 origin, d3 direction) {
+  double radius_squared = radius * radius;
+  d3 center_to_eye = sub(origin, location);
+  double a = -dp(direction, center_to_eye);
+  double delta = a * a - (len_squared(center_to_eye) - radius_squared);
+  if (!(delta >= 0)) return false;
+  if (delta == 0 || a >= 0.0000001) return a >= 0.0000001;
   double sqrtdelta = sqrt(delta);
   double t1 = a + sqrtdelta, t2 = a - sqrtdelta;
   return t1 >= 0.0000001 || t2 >= 0.0000001;

@@ -75,6 +75,7 @@ class TileComposer:
         self.frame = self.frames[0]
         self._flat = [f.view(torch.int32).view(-1) for f in self.frames]  # one element per pixel
         self._packed = [None, None]  # CUDA event per slot: own pixels have been read out
+        self._done = [None, None]    # CUDA event per slot: compose() has finished with frames[slot]
         if world == 1:
             return
         idx = [np.flatnonzero(owned_pixel_mask(width, height, r, world, tile_size).ravel()) for r in range(world)]
@@ -91,10 +92,17 @@ class TileComposer:
             self._peer_dst = torch.from_numpy(dst).to(device)
 
     def wait_slot(self, slot):
-        """Block until the previous compose() of `slot` has read the rank's pixels out of it."""
+        """Block the host until the previous compose() of `slot` has read the rank's pixels out of it."""
         ev = self._packed[slot]
         if ev is not None:
             ev.synchronize()
+
+    def slot_event(self, slot):
+        """CUDA event behind the last operation the previous compose() of `slot` enqueued on frames[slot] (the
+        read-out of the rank's own pixels; on rank 0 also the scatter of the peers' pixels), or None.  A renderer
+        orders its stream behind it (rtmi_scene_wait_event) before it writes frames[slot] again; the host does
+        not wait."""
+        return self._done[slot]
 
     def compose(self, slot=0):
         """Enqueue the gather of frames[slot]; returns rank 0's frame tensor (None on other ranks).
@@ -108,10 +116,15 @@ class TileComposer:
             ev = torch.cuda.Event()
             ev.record()
             self._packed[slot] = ev
+            self._done[slot] = ev
         if self.rank == 0:
             recv = self._recv[slot]
             dist.gather(send, list(recv.unbind(0)), dst=0, group=self.group)
             self._flat[slot].index_copy_(0, self._peer_dst, recv.view(-1).index_select(0, self._peer_src))
+            if self.device.type == "cuda":
+                ev = torch.cuda.Event()
+                ev.record()
+                self._done[slot] = ev
             return self.frames[slot]
         dist.gather(send, None, dst=0, group=self.group)
         return None
