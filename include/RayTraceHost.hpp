@@ -159,6 +159,13 @@ inline void raytraceWorld(v3d camera, v3d cameraDirection, double focalLength, i
       for (const auto& t : s->boundedShapes) ct.push_back(toC(t, materialIndex(t.material)));
       c.count = (int64_t)ct.size() - c.first;
     } else if (const Triangle* t = std::get_if<Triangle>(&o)) {
+      // consecutive triangles of the list form ONE run: the list order among them is the order of triangles[],
+      // and the kernels' per-ray loops over the top-level list then see one entry instead of thousands
+      if (!co.empty() && co.back().kind == RTMI_TRIANGLES && co.back().first + co.back().count == (int64_t)ct.size()) {
+        ct.push_back(toC(*t, materialIndex(t->material)));
+        co.back().count += 1;
+        continue;
+      }
       c.kind = RTMI_TRIANGLES;
       c.material = -1;
       c.first = (int64_t)ct.size();

@@ -50,8 +50,13 @@ public final class RtmiScene {
                 cObjects.append(rtmi_object(kind: Int32(RTMI_BOUNDING_SPHERE.rawValue), material: materialIndex(m), center: tuple(c), radius: r,
                                             first: first, count: Int64(cTriangles.count) - first))
             case let .triangle(a, b, c, m):
-                cObjects.append(rtmi_object(kind: Int32(RTMI_TRIANGLES.rawValue), material: -1, center: (0, 0, 0), radius: 0,
-                                            first: Int64(cTriangles.count), count: 1))
+                // consecutive triangles of the list form one run (their order is the order of cTriangles)
+                if let last = cObjects.last, last.kind == Int32(RTMI_TRIANGLES.rawValue), last.first + last.count == Int64(cTriangles.count) {
+                    cObjects[cObjects.count - 1].count += 1
+                } else {
+                    cObjects.append(rtmi_object(kind: Int32(RTMI_TRIANGLES.rawValue), material: -1, center: (0, 0, 0), radius: 0,
+                                                first: Int64(cTriangles.count), count: 1))
+                }
                 append(a, b, c, m)
             case let .light(index):
                 cObjects.append(rtmi_object(kind: Int32(RTMI_LIGHT.rawValue), material: -1, center: (0, 0, 0), radius: 0, first: Int64(index), count: 0))
@@ -75,9 +80,24 @@ public final class RtmiScene {
     deinit { rtmi_scene_destroy(handle) }
 }
 
-/// raytraceWorld (RayTracingFunctions.swift:145-180).  imageWidth/imageHeight are the reference's
-/// globals (ViewController.swift:13-14); the reference ignores its imageWidthPixels/imageHeightPixels
-/// arguments (:170) and so does this.
+/// The reference's globals (ViewController.swift:13-14).
+public var imageWidth = 1000
+public var imageHeight = 1000
+
+/// raytraceWorld with the reference's own argument list (RayTracingFunctions.swift:145-155), so that the call at
+/// ViewController.swift:160-179 stays as it is.  imageWidthPixels / imageHeightPixels and materialDictionary are
+/// accepted and ignored, as in the reference (:170 uses the globals; the dictionary is never read).  The scene is
+/// flattened and uploaded on every call; a caller that renders many frames of one scene keeps an RtmiScene and
+/// calls the overload below.
+public func raytraceWorld(camera: V3, cameraDirection: V3, focalLength: Double, imageWidthPixels: Int, imageHeightPixels: Int,
+                          ambientLight: Color, lights: [LightValues], objects: [SceneObject],
+                          materialDictionary: [String: MaterialValues], outputBitmap: inout [UInt8], pixelDone: (() -> Void)?) {
+    let scene = RtmiScene(lights: lights, objects: objects)
+    raytraceWorld(camera: camera, cameraDirection: cameraDirection, focalLength: focalLength, imageWidth: imageWidth,
+                  imageHeight: imageHeight, ambientLight: ambientLight, scene: scene, outputBitmap: &outputBitmap, pixelDone: pixelDone)
+}
+
+/// The same frame for a scene that is already resident on the GPU.
 public func raytraceWorld(camera: V3, cameraDirection: V3, focalLength: Double, imageWidth: Int, imageHeight: Int,
                           pixelSubdivision: Double = 1, ambientLight: Color, scene: RtmiScene,
                           outputBitmap: inout [UInt8], pixelDone: (() -> Void)? = nil) {

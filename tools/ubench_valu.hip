@@ -271,6 +271,87 @@ __global__ void __launch_bounds__(256) k_proto_trilane(const float* __restrict__
   hits[blockIdx.y * gridDim.x * 256 + blockIdx.x * 256 + threadIdx.x] = cnt;
 }
 
+// ---- the production cone loop: 3 packed FMA-class instructions per PAIR of triangles and ray --------------
+// A record holds 8 triangles as 4 pairs x 3 components x (triangle a, triangle b) = 12 f2 values (+4 padding);
+// a ray passes a triangle iff d . w >= 1.  R rays per lane, as in k_search_primary<R> / k_search_tree<R>.
+// (D) record operands wave-uniform from global memory: scalar loads, SGPR operands of v_pk_mul/v_pk_fma.
+template <int R>
+__global__ void __launch_bounds__(256) k_cone_sgpr(const f2* __restrict__ rec, int nrec, const float* __restrict__ rays,
+                                                    unsigned* hits) {
+  int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  float dx[R], dy[R], dz[R];
+  unsigned cnt = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    dx[r] = rays[(gid * R + r) * 3 + 0];
+    dy[r] = rays[(gid * R + r) * 3 + 1];
+    dz[r] = rays[(gid * R + r) * 3 + 2];
+  }
+  for (int b = 0; b < nrec; ++b) {
+    const f2* rp = rec + (size_t)b * 16;
+    f2 cur[12];
+#pragma unroll
+    for (int c = 0; c < 12; ++c) cur[c] = rp[c];
+#pragma unroll
+    for (int pr = 0; pr < 4; ++pr) {
+      f2 q[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) { f2 X = {dx[r], dx[r]}; q[r] = cur[pr * 3 + 0] * X; }
+#pragma unroll
+      for (int r = 0; r < R; ++r) { f2 Y = {dy[r], dy[r]}; q[r] = __builtin_elementwise_fma(cur[pr * 3 + 1], Y, q[r]); }
+#pragma unroll
+      for (int r = 0; r < R; ++r) { f2 Z = {dz[r], dz[r]}; q[r] = __builtin_elementwise_fma(cur[pr * 3 + 2], Z, q[r]); }
+      float ma = q[0].x, mb = q[0].y;
+#pragma unroll
+      for (int r = 1; r < R; ++r) { ma = __builtin_fmaxf(ma, q[r].x); mb = __builtin_fmaxf(mb, q[r].y); }
+      if (__builtin_expect(__any(__builtin_fmaxf(ma, mb) >= 1.0f), 0)) cnt += 1u;
+    }
+  }
+  hits[gid] = cnt;
+}
+
+// (E) the same loop with the records staged through LDS in chunks and read back with broadcast reads.
+template <int R>
+__global__ void __launch_bounds__(256) k_cone_lds(const f2* __restrict__ rec, int nrec, const float* __restrict__ rays,
+                                                   unsigned* hits) {
+  constexpr int CH = 64;  // records per chunk: 64 x 128 B = 8 KB
+  __shared__ f2 sm[CH * 16];
+  int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  float dx[R], dy[R], dz[R];
+  unsigned cnt = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    dx[r] = rays[(gid * R + r) * 3 + 0];
+    dy[r] = rays[(gid * R + r) * 3 + 1];
+    dz[r] = rays[(gid * R + r) * 3 + 2];
+  }
+  for (int c0 = 0; c0 < nrec; c0 += CH) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < CH * 16; i += blockDim.x) sm[i] = rec[(size_t)c0 * 16 + i];
+    __syncthreads();
+    for (int b = 0; b < CH; ++b) {
+      f2 cur[12];
+#pragma unroll
+      for (int c = 0; c < 12; ++c) cur[c] = sm[b * 16 + c];
+#pragma unroll
+      for (int pr = 0; pr < 4; ++pr) {
+        f2 q[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { f2 X = {dx[r], dx[r]}; q[r] = cur[pr * 3 + 0] * X; }
+#pragma unroll
+        for (int r = 0; r < R; ++r) { f2 Y = {dy[r], dy[r]}; q[r] = __builtin_elementwise_fma(cur[pr * 3 + 1], Y, q[r]); }
+#pragma unroll
+        for (int r = 0; r < R; ++r) { f2 Z = {dz[r], dz[r]}; q[r] = __builtin_elementwise_fma(cur[pr * 3 + 2], Z, q[r]); }
+        float ma = q[0].x, mb = q[0].y;
+#pragma unroll
+        for (int r = 1; r < R; ++r) { ma = __builtin_fmaxf(ma, q[r].x); mb = __builtin_fmaxf(mb, q[r].y); }
+        if (__builtin_expect(__any(__builtin_fmaxf(ma, mb) >= 1.0f), 0)) cnt += 1u;
+      }
+    }
+  }
+  hits[gid] = cnt;
+}
+
 template <typename F>
 static float time_ms(F launch, int reps = 5) {
   hipEvent_t e0, e1;
@@ -352,6 +433,45 @@ int main() {
     report("lds R=1", (double)blocks * 256 * 1 * ntri, ms);
     ms = time_ms([&] { hipLaunchKernelGGL(k_proto_lds<2>, dim3(blocks), dim3(256), 0, 0, dtri, ntri, dray, dh); });
     report("lds R=2", (double)blocks * 256 * 2 * ntri, ms);
+  }
+  {
+    // the production cone loop (3 packed FMA-class instructions per pair of triangles and ray): operands through
+    // scalar loads (what k_search_primary / k_search_tree do) against operands staged in LDS
+    const int nrec = ntri / 8;
+    std::vector<float> hrec((size_t)nrec * 32);
+    for (auto& v : hrec) v = (rand() / (float)RAND_MAX - 0.5f) * 0.5f;  // |d . w| stays below 1: nothing passes, as in the steady state
+    float* drec;
+    CK(hipMalloc(&drec, hrec.size() * 4));
+    CK(hipMemcpy(drec, hrec.data(), hrec.size() * 4, hipMemcpyHostToDevice));
+    auto report_cone = [&](const char* name, double pairs, float ms) {
+      double cyc = ms * 1e-3 * clk * cus * 4 / (pairs / 64.0);
+      printf("%-28s %8.3f ms  %.3e pairs/s  %.2f SIMD-cyc per wave-pair (1.5 packed FMA + 0.5 max => ideal 8.5)\n", name, ms,
+             pairs / (ms * 1e-3), cyc);
+    };
+    for (int bpc : {4, 8}) {
+      int blocks = cus * bpc;
+      printf("-- cone loop, blocks/CU %d\n", bpc);
+      float ms;
+      ms = time_ms([&] { hipLaunchKernelGGL(k_cone_sgpr<2>, dim3(blocks), dim3(256), 0, 0, (const f2*)drec, nrec, dray, dh); });
+      report_cone("cone sgpr R=2", (double)blocks * 256 * 2 * ntri, ms);
+      ms = time_ms([&] { hipLaunchKernelGGL(k_cone_lds<2>, dim3(blocks), dim3(256), 0, 0, (const f2*)drec, nrec, dray, dh); });
+      report_cone("cone lds R=2", (double)blocks * 256 * 2 * ntri, ms);
+    }
+    // R=4 needs twice the rays: a second ray buffer
+    float* dray4;
+    std::vector<float> hray4((size_t)256 * cus * 8 * 4 * 3);
+    for (auto& v : hray4) v = rand() / (float)RAND_MAX - 0.5f;
+    CK(hipMalloc(&dray4, hray4.size() * 4));
+    CK(hipMemcpy(dray4, hray4.data(), hray4.size() * 4, hipMemcpyHostToDevice));
+    for (int bpc : {4, 8}) {
+      int blocks = cus * bpc;
+      printf("-- cone loop, blocks/CU %d\n", bpc);
+      float ms;
+      ms = time_ms([&] { hipLaunchKernelGGL(k_cone_sgpr<4>, dim3(blocks), dim3(256), 0, 0, (const f2*)drec, nrec, dray4, dh); });
+      report_cone("cone sgpr R=4", (double)blocks * 256 * 4 * ntri, ms);
+      ms = time_ms([&] { hipLaunchKernelGGL(k_cone_lds<4>, dim3(blocks), dim3(256), 0, 0, (const f2*)drec, nrec, dray4, dh); });
+      report_cone("cone lds R=4", (double)blocks * 256 * 4 * ntri, ms);
+    }
   }
   {
     // lane = triangle: ntri/(256*T) blocks in x, rays split over y to fill the chip
