@@ -100,7 +100,12 @@ typedef struct {
 } rtmi_scene_desc;
 
 typedef enum {
-  RTMI_HIT_LIST_ORDER = 0 /* reference-exact: lowest list position that is hit */
+  RTMI_HIT_LIST_ORDER = 0, /* reference-exact: lowest list position that is hit */
+  RTMI_HIT_NEAREST = 1     /* extension, NOT the reference's behaviour: at the three places where the reference takes
+                              intersections[0] (RayTracingFunctions.swift:83, :93, :216) the intersection with the
+                              smallest parameter is taken, the first in list order among equal parameters; shadow rays
+                              (:236-243, "is anything hit") are unaffected.  Cone-tree search only
+                              (RTMI_SEARCH_LIST_SCAN: RTMI_ERR_UNSUPPORTED). */
 } rtmi_hit_policy;
 
 /* How the triangles of a group are searched for a primary ray.  Both give the same hits. */

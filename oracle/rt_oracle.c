@@ -266,8 +266,11 @@ typedef struct {
 /* traceRay over the top-level list (RTF:37-44) reduced to what its callers consume:
  * intersections[0] (RTF:83, :216) and whether any non-bounding object was hit (RTF:241).
  * The reference evaluates every object; the counters charge every object accordingly. */
+/* Hit policy: RTMI_HIT_LIST_ORDER is the reference (intersections[0], RTF:83, :93, :216).  RTMI_HIT_NEAREST is an
+ * extension: at those three places the intersection with the smallest `parameter` is taken instead, the first in
+ * list order among equal parameters.  Shadow rays (RTF:236-243: is anything hit at all) are the same in both. */
 static int trace_top(const rtmi_scene_desc* s, const list_stats* ls, v3 o, v3 d, isect* first,
-                     int* any_non_bounding, tally* tl) {
+                     int* any_non_bounding, tally* tl, int nearest) {
   double oo[3], dd[3];
   store(oo, o);
   store(dd, d);
@@ -277,7 +280,7 @@ static int trace_top(const rtmi_scene_desc* s, const list_stats* ls, v3 o, v3 d,
   tl->tri_tests += ls->top_tris;
   for (int64_t k = 0; k < s->n_objects; ++k) {
     const rtmi_object* ob = &s->objects[k];
-    if (any_non_bounding ? anb : found) break;
+    if (any_non_bounding ? anb : (found && !nearest)) break;
     switch (ob->kind) {
       case RTMI_SPHERE:
       case RTMI_BOUNDING_SPHERE: {
@@ -285,7 +288,7 @@ static int trace_top(const rtmi_scene_desc* s, const list_stats* ls, v3 o, v3 d,
         int32_t c = oracle_sphere_intersections(ob->center, ob->radius, oo, dd, t, P, n);
         if (c > 0) {
           if (ob->kind == RTMI_SPHERE) anb = 1;
-          if (!found) {
+          if (!found || (nearest && t[0] < first->t)) { /* a sphere's own roots are sorted near first (REN:265-271) */
             found = 1;
             first->point = V(P[0]);
             first->normal = V(n[0]);
@@ -304,7 +307,7 @@ static int trace_top(const rtmi_scene_desc* s, const list_stats* ls, v3 o, v3 d,
           double t, P[3], n[3];
           if (oracle_triangle_intersection(s->triangles[i].v, oo, dd, &t, P, n)) {
             anb = 1;
-            if (!found) {
+            if (!found || (nearest && t < first->t)) {
               found = 1;
               first->point = V(P);
               first->normal = V(n);
@@ -315,7 +318,7 @@ static int trace_top(const rtmi_scene_desc* s, const list_stats* ls, v3 o, v3 d,
               first->object = k;
               first->triangle = i;
             }
-            break; /* later triangles of the run cannot change [0] or the any-flag */
+            if (!nearest || any_non_bounding) break; /* later triangles of the run cannot change [0] or the any-flag */
           }
         }
         break;
@@ -324,7 +327,7 @@ static int trace_top(const rtmi_scene_desc* s, const list_stats* ls, v3 o, v3 d,
         double t, P[3];
         if (oracle_light_intersection(s->lights[ob->first].loc, oo, dd, &t, P)) {
           anb = 1;
-          if (!found) {
+          if (!found || (nearest && t < first->t)) {
             found = 1;
             first->point = V(P);
             first->has_normal = 0;
@@ -347,14 +350,17 @@ static int trace_top(const rtmi_scene_desc* s, const list_stats* ls, v3 o, v3 d,
 
 /* traceRay over getBoundedIntersectables() (RTF:86-93). */
 static int trace_children(const rtmi_scene_desc* s, const rtmi_object* ob, int64_t obj_index, v3 o,
-                          v3 d, isect* first, tally* tl) {
+                          v3 d, isect* first, tally* tl, int nearest) {
   double oo[3], dd[3];
   store(oo, o);
   store(dd, d);
   tl->tri_tests += ob->count;
+  int found = 0;
   for (int64_t i = ob->first; i < ob->first + ob->count; ++i) {
     double t, P[3], n[3];
     if (oracle_triangle_intersection(s->triangles[i].v, oo, dd, &t, P, n)) {
+      if (found && !(t < first->t)) continue;
+      found = 1;
       first->point = V(P);
       first->normal = V(n);
       first->has_normal = 1;
@@ -363,17 +369,17 @@ static int trace_children(const rtmi_scene_desc* s, const rtmi_object* ob, int64
       first->is_bounding = 0;
       first->object = obj_index;
       first->triangle = i;
-      return 1;
+      if (!nearest) return 1;
     }
   }
-  return 0;
+  return found;
 }
 
 typedef struct { double r, g, b; } rgb;
 
 /* calculateLighting, RTF:182-271. */
 static rgb calculate_lighting(const rtmi_scene_desc* s, const list_stats* ls, const isect* is,
-                              const double ambient[3], v3 camera, int reflect, tally* tl) {
+                              const double ambient[3], v3 camera, int reflect, tally* tl, int nearest) {
   v3 surface_point = is->point;
   const rtmi_material* material = is->material >= 0 ? &s->materials[is->material] : NULL;
 
@@ -394,8 +400,8 @@ static rgb calculate_lighting(const rtmi_scene_desc* s, const list_stats* ls, co
     rgb contribution = {0.0, 0.0, 0.0};
     isect rh;
     tl->rays_reflection += 1;
-    if (trace_top(s, ls, surface_point, reflection, &rh, NULL, tl)) {
-      contribution = calculate_lighting(s, ls, &rh, ambient, surface_point, 0, tl);
+    if (trace_top(s, ls, surface_point, reflection, &rh, NULL, tl, nearest)) {
+      contribution = calculate_lighting(s, ls, &rh, ambient, surface_point, 0, tl, nearest);
     }
     I.r = I.r + contribution.r;
     I.g = I.g + contribution.g;
@@ -410,7 +416,7 @@ static rgb calculate_lighting(const rtmi_scene_desc* s, const list_stats* ls, co
     isect dummy;
     int any_non_bounding = 0;
     tl->rays_shadow += 1;
-    trace_top(s, ls, surface_point, point_to_light, &dummy, &any_non_bounding, tl);
+    trace_top(s, ls, surface_point, point_to_light, &dummy, &any_non_bounding, tl, nearest);
     if (any_non_bounding) continue; /* RTF:241 */
     if (!material) continue;        /* RTF:245 */
     /* RTF:246-249 */
@@ -438,7 +444,7 @@ static int validate(const rtmi_scene_desc* s, const rtmi_params* p) {
   if (!s || !p) return RTMI_ERR_INVALID_ARGUMENT;
   if (p->width < 2 || p->height < 2) return RTMI_ERR_INVALID_ARGUMENT;
   if (!(p->pixel_subdivision > 0.0) || p->pixel_subdivision > 1.0) return RTMI_ERR_INVALID_ARGUMENT;
-  if (p->hit_policy != RTMI_HIT_LIST_ORDER) return RTMI_ERR_UNSUPPORTED;
+  if (p->hit_policy != RTMI_HIT_LIST_ORDER && p->hit_policy != RTMI_HIT_NEAREST) return RTMI_ERR_UNSUPPORTED;
   for (int64_t k = 0; k < s->n_objects; ++k) {
     const rtmi_object* ob = &s->objects[k];
     if (ob->material >= s->n_materials) return RTMI_ERR_INVALID_ARGUMENT;
@@ -493,11 +499,12 @@ int32_t oracle_render(const rtmi_scene_desc* s, const rtmi_camera* cam, const rt
 
   tally total = {0, 0, 0, 0, 0, 0};
   if (threads < 1) threads = 1;
+  const int nearest = p->hit_policy == RTMI_HIT_NEAREST;
 
 #pragma omp parallel num_threads(threads)
   {
     tally tl = {0, 0, 0, 0, 0, 0};
-    double* ij = (double*)malloc(sizeof(double) * 2 * (size_t)spp);
+    double* ij = (double*)malloc(sizeof(double) * 2 * 64 * 64);
 #pragma omp for schedule(dynamic, 1)
     for (int32_t x = x0; x < x1; ++x) {     /* WCS:68-89: x outer ... */
       for (int32_t y = y0; y < y1; ++y) {   /* ... y inner */
@@ -505,9 +512,11 @@ int32_t oracle_render(const rtmi_scene_desc* s, const rtmi_camera* cam, const rt
           int32_t tile = (y / ts) * tiles_x + (x / ts);
           if (tile % world != p->tile_rank) continue;
         }
-        oracle_pixel_samples(x, y, p->pixel_subdivision, ij, spp);
+        /* the stride's count can differ from pixel (0,0)'s when some k*s lies within a rounding error of 1;
+         * the pixel's own samples are traced and averaged (hit ids beyond the frame's count are not recorded) */
+        const int32_t npx = oracle_pixel_samples(x, y, p->pixel_subdivision, ij, 64 * 64);
         rgb cumulative = {0.0, 0.0, 0.0}; /* UTL:56 */
-        for (int32_t k = 0; k < spp; ++k) { /* RTF:72 */
+        for (int32_t k = 0; k < npx; ++k) { /* RTF:72 */
           double fp[3];
           oracle_pixel_to_world(ul, u, v, ppw_h, ppw_v, ij[2 * k], ij[2 * k + 1], fp);
           v3 c2p = normalize(sub(V(fp), camera)); /* RTF:73 */
@@ -515,23 +524,23 @@ int32_t oracle_render(const rtmi_scene_desc* s, const rtmi_camera* cam, const rt
           rgb value = {0.0, 0.0, 0.0}; /* RGB.black, RTF:79,90 */
           int32_t id = -1;
           isect i1;
-          if (trace_top(s, &ls, camera, c2p, &i1, NULL, &tl)) { /* RTF:76-83 */
+          if (trace_top(s, &ls, camera, c2p, &i1, NULL, &tl, nearest)) { /* RTF:76-83 */
             int have = 1;
             if (i1.is_bounding) { /* RTF:85-94 */
-              have = trace_children(s, &s->objects[i1.object], i1.object, camera, c2p, &i1, &tl);
+              have = trace_children(s, &s->objects[i1.object], i1.object, camera, c2p, &i1, &tl, nearest);
             }
             if (have) {
               tl.primary_hits += 1;
-              value = calculate_lighting(s, &ls, &i1, p->ambient, camera, 1, &tl); /* RTF:96 */
+              value = calculate_lighting(s, &ls, &i1, p->ambient, camera, 1, &tl, nearest); /* RTF:96 */
               id = i1.triangle >= 0 ? (int32_t)i1.triangle : (int32_t)(-2 - i1.object);
             }
           }
           cumulative.r = cumulative.r + value.r; /* UTL:57-59 */
           cumulative.g = cumulative.g + value.g;
           cumulative.b = cumulative.b + value.b;
-          if (hit_id) hit_id[((size_t)y * W + x) * spp + k] = id;
+          if (hit_id && k < spp) hit_id[((size_t)y * W + x) * spp + k] = id;
         }
-        double factor = 1 / (double)spp; /* UTL:61-62 */
+        double factor = 1 / (double)npx; /* UTL:61-62 */
         double ar = factor * cumulative.r, ag = factor * cumulative.g, ab = factor * cumulative.b;
         size_t first_byte = (size_t)bytes_per_row * y + (size_t)x * 4; /* RTF:106-107 */
         rgba[first_byte] = (uint8_t)(255 * ar);                          /* RTF:108-111 */

@@ -258,6 +258,12 @@ def trace_ray(origin, direction, objects, out):  # :37-44
         o.intersections(origin, direction, out)
 
 
+def pick(hits, nearest):
+    """The intersection a caller of traceRay goes on with: intersections[0] in the reference (:83, :93, :216);
+    with the nearest-hit extension the one with the smallest parameter (min() keeps the first among equals)."""
+    return min(hits, key=lambda h: h.parameter) if nearest else hits[0]
+
+
 def get_plane_vectors(direction):  # :46-57
     plane_normal = normalize(-direction)
     up = normalize(V3(0, 1, -1))
@@ -266,7 +272,7 @@ def get_plane_vectors(direction):  # :46-57
     return u, v
 
 
-def calculate_lighting(isect, ambient_light, lights, camera, objects, reflect=True, counters=None):  # :182-271
+def calculate_lighting(isect, ambient_light, lights, camera, objects, reflect=True, counters=None, nearest=False):  # :182-271
     surface_point = isect.point
     material = isect.object.material
     intensity = RGB(0, 0, 0)
@@ -286,7 +292,7 @@ def calculate_lighting(isect, ambient_light, lights, camera, objects, reflect=Tr
             counters["rays_reflection"] += 1
         trace_ray(surface_point, reflection, objects, hits)
         if hits:
-            contribution = calculate_lighting(hits[0], ambient_light, lights, surface_point, objects, False, counters)
+            contribution = calculate_lighting(pick(hits, nearest), ambient_light, lights, surface_point, objects, False, counters, nearest)
         intensity.add(contribution)
     for light in lights:
         point_to_light = normalize(light.location - surface_point)
@@ -356,7 +362,7 @@ def to_u8(c):
     return int(255 * c)
 
 
-def raytrace_world(camera, camera_direction, focal_length, width, height, subdivision, ambient, lights, objects):
+def raytrace_world(camera, camera_direction, focal_length, width, height, subdivision, ambient, lights, objects, nearest=False):
     """raytraceWorld + raytracePixels (:145-180, :59-114) with the frame size and the subdivision as arguments.
     Returns (rgba rows as nested lists [H][W][4] or None where nothing is written, hit ids [H][W][spp], counters)."""
     center = camera + camera_direction.times(focal_length)
@@ -381,7 +387,7 @@ def raytrace_world(camera, camera_direction, focal_length, width, height, subdiv
                 values.append(RGB(0, 0, 0))
                 ids.append(-1)
                 continue
-            i1 = hits[0]
+            i1 = pick(hits, nearest)
             if i1.object.isBounding:
                 inner = []
                 trace_ray(camera, d, i1.object.getBoundedIntersectables(), inner)
@@ -389,9 +395,9 @@ def raytrace_world(camera, camera_direction, focal_length, width, height, subdiv
                     values.append(RGB(0, 0, 0))
                     ids.append(-1)
                     continue
-                i1 = inner[0]
+                i1 = pick(inner, nearest)
             counters["primary_hits"] += 1
-            values.append(calculate_lighting(i1, ambient, lights, camera, objects, True, counters))
+            values.append(calculate_lighting(i1, ambient, lights, camera, objects, True, counters, nearest))
             ids.append(i1.object.ident)
         avg = average(values)
         rgba[y][x] = [to_u8(avg.red), to_u8(avg.green), to_u8(avg.blue), 255]
@@ -440,7 +446,7 @@ def render(data, camera, params):
     lights, objects = build_scene(data)
     amb = RGB(*[float(x) for x in params.ambient])
     return raytrace_world(V3(*camera.pos), V3(*camera.dir), float(camera.focal_length), params.width, params.height,
-                          float(params.pixel_subdivision), amb, lights, objects)
+                          float(params.pixel_subdivision), amb, lights, objects, nearest=params.hit_policy == 1)
 
 
 # ---- ObjLoader.swift, ViewController.swift:107-120 ----------------------------------------------

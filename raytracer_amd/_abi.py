@@ -20,6 +20,7 @@ RTMI_BOUNDING_SPHERE = 2
 RTMI_LIGHT = 3
 
 RTMI_HIT_LIST_ORDER = 0
+RTMI_HIT_NEAREST = 1
 
 D3 = C.c_double * 3
 

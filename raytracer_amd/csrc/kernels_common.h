@@ -47,6 +47,7 @@ struct FrameConst {
   int tile_size, tiles_x, tile_rank, tile_world;
   // per entry of the block list: 0 = no sample of the block can hit anything (k_block_cull); null = every block is live
   const unsigned char* block_live;
+  int nearest;  // hit policy of the frame: 0 = first in list order (the reference), 1 = smallest parameter
 };
 
 // Work counters are striped over NSLOT slots (two 64-byte lines per slot) so that the

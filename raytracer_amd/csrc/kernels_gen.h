@@ -48,7 +48,7 @@ k_block_cull(FrameConst fc, const int2* __restrict__ blocks, int nblocks, unsign
 
 __global__ void __launch_bounds__(256)
 k_gen(FrameConst fc, SceneDev sc, const int2* __restrict__ blocks, int nsamples, int* hit_id, double* dirs,
-      int* q_child, int* q_shade, int* q_top, DevCounters* cnt) {
+      int* q_child, int* q_shade, int* q_top, DevCounters* cnt, double* t_obj) {
   // queue entries are staged in LDS and flushed with one global atomic per queue per workgroup
   __shared__ int lq[3][256 * GEN_ITERS];
   __shared__ int ln[3];
@@ -92,7 +92,16 @@ k_gen(FrameConst fc, SceneDev sc, const int2* __restrict__ blocks, int nsamples,
     if (live) {
       ++n_traced;
       d3 d = sample_dir(fc, x, y, kx, ky);
-      int obj = first_sphere_like(sc, rtx::ld3(fc.cam), d);
+      int obj;
+      if (fc.nearest) {
+        double t;
+        obj = nearest_sphere_like(sc, rtx::ld3(fc.cam), d, &t);
+        // with top-level triangle runs k_resolve_top compares this parameter with the nearest triangle's
+        // (t_obj is the colour array, which nothing else uses before shading)
+        if (obj >= 0 && has_top) t_obj[(size_t)s * 3] = t;
+      } else {
+        obj = first_sphere_like(sc, rtx::ld3(fc.cam), d);
+      }
       if (obj >= 0) {
         id = -2 - obj;
         if (sc.objects[obj].kind == RTMI_BOUNDING_SPHERE) to_child = true; else to_shade = true;
@@ -136,7 +145,8 @@ k_gen(FrameConst fc, SceneDev sc, const int2* __restrict__ blocks, int nsamples,
 // k_gen) with the first top-level triangle (tri_hit) by list position.
 __global__ void __launch_bounds__(256)
 k_resolve_top(SceneDev sc, const int* __restrict__ q_top, const int* __restrict__ nq_ptr, const int* __restrict__ tri_hit,
-              const int* __restrict__ tri_owner, int* hit_id, int* q_child, int* q_shade, DevCounters* cnt) {
+              const int* __restrict__ tri_owner, int* hit_id, int* q_child, int* q_shade, DevCounters* cnt,
+              const double* __restrict__ tval, const double* __restrict__ t_obj, int nearest) {
   int q = blockIdx.x * blockDim.x + threadIdx.x;
   bool to_child = false, to_shade = false;
   int s = -1;
@@ -146,7 +156,15 @@ k_resolve_top(SceneDev sc, const int* __restrict__ q_top, const int* __restrict_
     int th = tri_hit[q];
     if (th >= 0) th = checked(th, sc.n_tris, cnt, 15);
     int obj = id <= -2 ? -2 - id : 0x7fffffff;
-    if (th >= 0 && tri_owner[th] < obj) { id = th; obj = -1; }
+    if (th >= 0) {
+      const int owner = tri_owner[th];
+      bool take = owner < obj;  // list order (also: no sphere-like hit at all)
+      if (nearest && id <= -2) {  // the smaller parameter wins, list order among equals
+        const double tt = tval[s], to = t_obj[(size_t)s * 3];
+        take = tt < to || (tt == to && owner < obj);
+      }
+      if (take) { id = th; obj = -1; }
+    }
     hit_id[s] = id;
     if (id >= 0) to_shade = true;
     else if (id <= -2) {

@@ -53,6 +53,7 @@ struct SearchArgs {
   int* best_pos;     // per sample: lowest list position hit so far (tree search)
   int2* cand;        // (sample, list position) candidates of the tree search, NSLOT lists of cand_cap / NSLOT
   int cand_cap;
+  int nearest;       // hit policy: 1 = the hit with the smallest parameter wins (tree search only)
   TreeDev tree;
 };
 

@@ -35,6 +35,24 @@ __device__ inline int first_sphere_like(const SceneDev& sc, d3 o, d3 d) {
   return -1;
 }
 
+// Nearest-hit policy: the sphere-like member whose first intersection has the smallest parameter (the first in
+// list order among equal parameters); -1 if none.  A sphere's own roots are sorted near first (REN:265-271).
+__device__ inline int nearest_sphere_like(const SceneDev& sc, d3 o, d3 d, double* t_out) {
+  int best = -1;
+  double best_t = 0.0;
+  for (int k = 0; k < sc.n_objects; ++k) {
+    const rtmi_object& ob = sc.objects[k];
+    double t;
+    d3 P, n;
+    bool hit = false;
+    if (ob.kind == RTMI_SPHERE || ob.kind == RTMI_BOUNDING_SPHERE) hit = rtx::sphere_first_raw(rtx::ld3(ob.center), ob.radius, o, d, &t, &P, &n);
+    else if (ob.kind == RTMI_LIGHT) hit = rtx::light_hit(rtx::ld3(sc.lights[ob.first].loc), o, d, &t, &P);
+    if (hit && (best < 0 || t < best_t)) { best = k; best_t = t; }
+  }
+  *t_out = best_t;
+  return best;
+}
+
 // The bounding-sphere tree of the top-level triangle runs as the shading kernels see it.  The
 // three arrays are separate __restrict__ kernel arguments (that is what lets the compiler fetch
 // records through scalar loads in kernels that also store).
@@ -239,6 +257,211 @@ __device__ inline bool trace_top_secondary(const SceneDev& sc, const TopTreeRef&
         anb = true;
         const int ti = min(max(sc.top_group[g], 0), sc.n_tris - 1);
         if (want_first && sc.tri_owner[ti] < first_obj) {
+          found = true;
+          const TriPlane pl = sc.planes[ti];
+          h->P = P; h->n = rtx::mk(pl.nx, pl.ny, pl.nz); h->t = t; h->has_normal = 1; h->n_unit = 1;
+          h->material = sc.tris[ti].material; h->id = ti;
+        }
+      }
+    }
+  }
+  *any_non_bounding = anb;
+  return found;
+}
+
+// Nearest-hit policy (an extension; the reference's list-order functions above are left as they are): a copy of
+// top_tree_trace in which the hit with the smallest parameter wins, the lower ordinal among equal parameters.
+// A general-origin ray (reflection or shadow ray) against ALL top-level triangles: the ordinal of
+// the hit that comes first in list order (any_only: of some hit), or -1.  The lanes that call this
+// together walk the tree together, like k_search_tree: a record of eight bounding spheres is
+// evaluated for every calling lane's own ray (packed line-sphere test, two spheres per
+// instruction), and a child is entered if some lane passes.  At a leaf the per-triangle cascade
+// of k_pack_general follows, then rtx::tri_hit in FP64.  Called from divergent shading code: the
+// wave-level votes only see the lanes that are tracing.
+__device__ inline int top_tree_trace_nearest(const SceneDev& sc, const TopTreeRef& T, d3 o, d3 d, bool any_only, double* t_out,
+                                     d3* P_out, tally_t* n_tests) {
+  const bool nearest = !any_only;  // the hit with the smallest parameter instead of the lowest ordinal
+  double best_t = 0.0;
+  const float ox = (float)(o.x - sc.c0[0]), oy = (float)(o.y - sc.c0[1]), oz = (float)(o.z - sc.c0[2]);
+  const float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
+  const float ndo = -(dx * ox + dy * oy + dz * oz);
+  const float noo = -(ox * ox + oy * oy + oz * oz);
+  const float o2x = 2.0f * ox, o2y = 2.0f * oy, o2z = 2.0f * oz;
+  const float mx_ = oy * dz - oz * dy, my_ = oz * dx - ox * dz, mz_ = ox * dy - oy * dx;  // o x d for the edge tests
+  const f2 X = {dx, dx}, Y = {dy, dy}, Z = {dz, dz}, N0 = {ndo, ndo};
+  const f2 OX = {o2x, o2x}, OY = {o2y, o2y}, OZ = {o2z, o2z}, N1 = {noo, noo};
+  int best = 0x7fffffff;  // ordinal of the best hit so far
+  unsigned int leaf_visits = 0;
+
+  // line-sphere values of the record's pair `pr`: passes iff !(U < 0)
+  auto pair_u = [&](const f2* rp, int pr) {
+    const f2 cx = rp[pr * 4 + 0], cy = rp[pr * 4 + 1], cz = rp[pr * 4 + 2], nk = rp[pr * 4 + 3];
+    f2 A = __builtin_elementwise_fma(cz, Z, __builtin_elementwise_fma(cy, Y, __builtin_elementwise_fma(cx, X, N0)));
+    f2 B = __builtin_elementwise_fma(cz, OZ, __builtin_elementwise_fma(cy, OY, __builtin_elementwise_fma(cx, OX, N1)));
+    return __builtin_elementwise_fma(A, A, B) + nk;
+  };
+  auto level_off = [&](int lvl) {
+    return lvl == 1 ? T.off[1] : lvl == 2 ? T.off[2] : lvl == 3 ? T.off[3] : lvl == 4 ? T.off[4] : lvl == 5 ? T.off[5]
+         : lvl == 6 ? T.off[6] : T.off[7];
+  };
+  auto eval = [&](int lvl, int ri) -> unsigned {
+    const f2* rp = T.rec + (size_t)min(level_off(lvl) + ri, T.n_records - 1) * (REC_DWORDS / 2);  // the clamp never binds
+    const bool live = !any_only || best == 0x7fffffff;
+    unsigned mask = 0;
+#pragma unroll
+    for (int pr = 0; pr < 4; ++pr) {
+      f2 U = pair_u(rp, pr);
+      if (__any(live && !(U.x < 0.0f))) mask |= 1u << (2 * pr);
+      if (__any(live && !(U.y < 0.0f))) mask |= 2u << (2 * pr);
+    }
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)mask);
+  };
+  auto leaf = [&](int ri) {
+    if ((unsigned)(ri * 8) >= (unsigned)T.n_slots) return;  // cannot happen (absent nodes never pass); keeps a bad record from becoming a bad address
+    const f2* rp = T.rec + (size_t)(T.off[0] + ri) * (REC_DWORDS / 2);
+    const bool live = !any_only || best == 0x7fffffff;
+    if (live) ++leaf_visits;
+#pragma unroll
+    for (int pr = 0; pr < 4; ++pr) {
+      f2 U = pair_u(rp, pr);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float u = h ? U.y : U.x;
+        bool cand = live && !(u < 0.0f);
+        if (!__any(cand)) continue;
+        const int g = T.slot_pos[ri * 8 + pr * 2 + h];  // top-level ordinal
+        if ((unsigned)g >= (unsigned)sc.n_top_tris) continue;  // padding slot (its sphere passes nothing; belt and braces)
+        // a later list position cannot replace the hit (under the nearest-hit policy any triangle can)
+        cand = cand && (any_only ? best == 0x7fffffff : (nearest || g < best));
+        if (!__any(cand)) continue;
+        const float* s2 = T.gst2 + (size_t)g * GST2_FLOATS;
+        {
+          const float nx = s2[0], ny = s2[1], nz = s2[2], cpl = s2[3], Ea = s2[4], Eb = s2[5];
+          float nd = __builtin_fmaf(nz, dz, __builtin_fmaf(ny, dy, nx * dx));
+          float no = __builtin_fmaf(nz, oz, __builtin_fmaf(ny, oy, nx * ox)) - cpl;
+          cand = cand && (nd <= Ea) && (no >= -Eb);
+        }
+        if (!__any(cand)) continue;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+          const float* w = s2 + 9 + e * 6;
+          float sv = __builtin_fmaf(w[2], dz, __builtin_fmaf(w[1], dy, w[0] * dx));
+          sv = __builtin_fmaf(w[5], mz_, __builtin_fmaf(w[4], my_, __builtin_fmaf(w[3], mx_, sv)));
+          cand = cand && (sv <= s2[6 + e]);
+        }
+        if (!__any(cand)) continue;
+        if (cand) {
+          const int ti = min(max(sc.top_group[g], 0), sc.n_tris - 1);  // the clamps never bind
+          const rtmi_triangle& tr = sc.tris[ti];
+          double t;
+          d3 P;
+          if (rtx::tri_hit(rtx::ld3(tr.v[0]), rtx::ld3(tr.v[1]), rtx::ld3(tr.v[2]), sc.planes[ti], o, d, &t, &P)) {
+            if (!nearest || best == 0x7fffffff || t < best_t || (t == best_t && g < best)) {
+              best = g;
+              best_t = t;
+              *t_out = t;
+              *P_out = P;
+            }
+          }
+        }
+      }
+    }
+  };
+
+  const int ltop = T.ltop;
+  bool done = false;
+  for (int t = 0; t < T.n_root && !done; ++t) {
+    if (ltop == 0) {
+      leaf(t);
+      done = any_only && !__any(best == 0x7fffffff);
+      continue;
+    }
+    int lvl = ltop, ri = t;
+    unsigned long long masks = (unsigned long long)eval(lvl, ri) << (8 * lvl);
+    for (;;) {
+      const unsigned cur = (unsigned)(masks >> (8 * lvl)) & 0xffu;
+      if (cur == 0) {
+        if (lvl == ltop) break;
+        ++lvl;
+        ri >>= 3;
+        continue;
+      }
+      const int c = __builtin_ctz(cur);
+      masks &= ~(1ull << (8 * lvl + c));
+      const int child = ri * 8 + c;
+      if (lvl == 1) {
+        leaf(child);
+        if (any_only && !__any(best == 0x7fffffff)) { done = true; break; }  // every tracing lane has its hit
+      } else {
+        --lvl;
+        ri = child;
+        masks |= (unsigned long long)eval(lvl, ri) << (8 * lvl);
+      }
+    }
+  }
+  *n_tests += 8u * leaf_visits;  // (ray, triangle) sphere tests this lane's ray took part in
+  return best == 0x7fffffff ? -1 : best;
+}
+
+// Nearest-hit policy: traceRay over the whole top-level list for a secondary
+// ray: intersections[0] if want_first, and whether any non-bounding object is hit.
+template <bool HAS_TOP>
+__device__ inline bool trace_top_secondary_nearest(const SceneDev& sc, const TopTreeRef& tt, d3 o, d3 d, bool want_first, Hit* h,
+                                           bool* any_non_bounding, tally_t* n_tests) {
+  bool found = false, anb = false;
+  constexpr bool nearest = true;  // want_first only: the smallest parameter wins, list order among equals
+  // spheres, bounding spheres and lights first, in list order: for a shadow ray the first
+  // non-bounding hit settles the question and the triangles need not be searched
+  int first_obj = 0x7fffffff;  // list index of the first sphere-like hit (want_first)
+#pragma nounroll
+  for (int k = 0; k < sc.n_objects; ++k) {
+    if (want_first ? (!nearest && found) : anb) break;
+    const rtmi_object& ob = sc.objects[k];
+    if (ob.kind == RTMI_SPHERE || ob.kind == RTMI_BOUNDING_SPHERE) {
+      double t;
+      d3 P, n;
+      if (want_first) {
+        if (rtx::sphere_first_raw(rtx::ld3(ob.center), ob.radius, o, d, &t, &P, &n) && (!nearest || !found || t < h->t)) {
+          found = true;
+          first_obj = k;
+          // without a material only the SIGN of normal.light is ever read (calculate_lighting)
+          h->n_unit = ob.material >= 0;
+          h->P = P; h->n = h->n_unit ? rtx::normalize(n) : n; h->t = t; h->has_normal = 1;
+          h->material = ob.material; h->id = -2 - k;
+        }
+      } else if (ob.kind == RTMI_SPHERE) {
+        if (rtx::sphere_any(rtx::ld3(ob.center), ob.radius, o, d)) anb = true;
+      }
+    } else if (ob.kind == RTMI_LIGHT) {
+      double t;
+      d3 P;
+      if (rtx::light_hit(rtx::ld3(sc.lights[ob.first].loc), o, d, &t, &P)) {
+        anb = true;
+        if (want_first && (!nearest || !found || t < h->t)) {
+          found = true;
+          first_obj = k;
+          h->P = P; h->t = t; h->has_normal = 0; h->n_unit = 1; h->material = -1; h->id = -2 - k;
+        }
+      }
+    }
+  }
+  if constexpr (HAS_TOP) {
+    // the top-level triangles: one walk for all runs; a triangle hit wins over the sphere-like
+    // hit if its run is listed earlier (RTF:41-43: the first intersection in list order)
+    if (want_first || !anb) {
+      double t;
+      d3 P;
+      const int g = top_tree_trace_nearest(sc, tt, o, d, !want_first, &t, &P, n_tests);
+      if (g >= 0) {
+        anb = true;
+        const int ti = min(max(sc.top_group[g], 0), sc.n_tris - 1);
+        bool take = false;
+        if (want_first) {
+          const int owner = sc.tri_owner[ti];
+          if constexpr (nearest) take = found ? (t < h->t || (t == h->t && owner < first_obj)) : true;
+          else take = owner < first_obj;
+        }
+        if (take) {
           found = true;
           const TriPlane pl = sc.planes[ti];
           h->P = P; h->n = rtx::mk(pl.nx, pl.ny, pl.nz); h->t = t; h->has_normal = 1; h->n_unit = 1;

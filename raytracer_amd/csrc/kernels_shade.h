@@ -67,6 +67,15 @@ __device__ inline int count_facing_lights(const SceneDev& sc, d3 P, d3 n, bool n
   return c;
 }
 
+// traceRay for a secondary ray under the frame's hit policy (the two functions are separate on purpose: the
+// reference's list-order code stays exactly as it was measured).
+template <bool HAS_TOP, bool NEAREST>
+__device__ __forceinline__ bool trace_secondary(const SceneDev& sc, const TopTreeRef& tt, d3 o, d3 d, bool want_first, Hit* h,
+                                                bool* any_non_bounding, tally_t* n_tests) {
+  if constexpr (NEAREST) return trace_top_secondary_nearest<HAS_TOP>(sc, tt, o, d, want_first, h, any_non_bounding, n_tests);
+  else return trace_top_secondary<HAS_TOP>(sc, tt, o, d, want_first, h, any_non_bounding, n_tests);
+}
+
 // LEAN (with REFLECT only): the instantiation for the common case that (1) the reflected ray finds nothing
 // whose lighting has to be evaluated -- no hit, a light, or an object without a material, whose contribution
 // is exactly zero (RTF:192, :245) -- and (2) the specular exponent is a small whole number.  It leaves the
@@ -78,8 +87,8 @@ __device__ inline int count_facing_lights(const SceneDev& sc, d3 P, d3 n, bool n
 // changes a pixel -- a bounding sphere blocks no light (RTF:241) and, lacking a material, reflects none
 // (RTF:192, :245) -- so the rays are neither traced nor counted (the caller asked for pixels, not for the
 // reference's ray statistics: RTMI_FLAG_NO_RAY_STATISTICS).
-template <bool REFLECT, bool HAS_TOP, bool LEAN = false, bool INERT = false>
-__device__ RGBd calculate_lighting(const SceneDev& sc, const TopTreeRef& tt, const ShadeConst& fc, const Hit& is, d3 camera,
+template <bool REFLECT, bool HAS_TOP, bool LEAN = false, bool INERT = false, bool NEAREST = false>
+__device__ __forceinline__ RGBd calculate_lighting(const SceneDev& sc, const TopTreeRef& tt, const ShadeConst& fc, const Hit& is, d3 camera,
                                    tally_t* n_refl, tally_t* n_shadow, tally_t* n_tests, tally_t* n_elided, bool* defer = nullptr) {
   d3 surface_point = is.P;
   RGBd I = {0.0, 0.0, 0.0};
@@ -121,7 +130,7 @@ __device__ RGBd calculate_lighting(const SceneDev& sc, const TopTreeRef& tt, con
       // contribution stays zero
     } else if constexpr (LEAN) {
       tally_t nt = 0;
-      if (trace_top_secondary<HAS_TOP>(sc, tt, surface_point, reflection, true, &rh, &anb, &nt)) {
+      if (trace_secondary<HAS_TOP, NEAREST>(sc, tt, surface_point, reflection, true, &rh, &anb, &nt)) {
         if (rh.has_normal && rh.material >= 0) {
           *defer = true;
           return I;
@@ -136,8 +145,9 @@ __device__ RGBd calculate_lighting(const SceneDev& sc, const TopTreeRef& tt, con
       *n_tests += nt;
     } else {
       *n_refl += 1;
-      if (trace_top_secondary<HAS_TOP>(sc, tt, surface_point, reflection, true, &rh, &anb, n_tests)) {
-        contribution = calculate_lighting<false, HAS_TOP>(sc, tt, fc, rh, surface_point, n_refl, n_shadow, n_tests, n_elided);
+      if (trace_secondary<HAS_TOP, NEAREST>(sc, tt, surface_point, reflection, true, &rh, &anb, n_tests)) {
+        contribution = calculate_lighting<false, HAS_TOP, false, false, NEAREST>(sc, tt, fc, rh, surface_point, n_refl, n_shadow, n_tests,
+                                                                                 n_elided);
       }
     }
     I.r = I.r + contribution.r;
@@ -166,7 +176,7 @@ __device__ RGBd calculate_lighting(const SceneDev& sc, const TopTreeRef& tt, con
       Hit dummy;
       bool anb = false;
       *n_shadow += 1;
-      trace_top_secondary<HAS_TOP>(sc, tt, surface_point, point_to_light, false, &dummy, &anb, n_tests);
+      trace_secondary<HAS_TOP, NEAREST>(sc, tt, surface_point, point_to_light, false, &dummy, &anb, n_tests);
       if (anb) continue;           // RTF:241
     }
     if (!has_material) continue; // RTF:245
@@ -204,7 +214,7 @@ __device__ inline void shade_tally_flush(DevCounters* cnt, const ShadeTally& t) 
 // Shade sample s whose primary ray (direction d) hit `id` (triangle index, or -2 - object index);
 // t_tri is the triangle's intersection parameter.  LEAN: returns true, with nothing counted or stored,
 // if the sample needs the full instantiation (see calculate_lighting).
-template <bool HAS_TOP, bool LEAN = false>
+template <bool HAS_TOP, bool LEAN = false, bool NEAREST = false>
 __device__ __forceinline__ bool shade_sample(const ShadeConst& fc, const SceneDev& sc, const TopTreeRef& tt, int s, d3 d,
                                              int id, double t_tri, double* rgb, ShadeTally* tl) {
   d3 cam = rtx::ld3(fc.cam);
@@ -242,7 +252,7 @@ __device__ __forceinline__ bool shade_sample(const ShadeConst& fc, const SceneDe
   if (ok) {
     bool defer = false;
     static_assert(!LEAN, "the lean lighting needs a wave-uniform material: shade_triangle_lean");
-    c = calculate_lighting<true, HAS_TOP, false>(sc, tt, fc, h, cam, &tl->n_refl, &tl->n_shadow, &tl->n_tests, &tl->n_elided,
+    c = calculate_lighting<true, HAS_TOP, false, false, NEAREST>(sc, tt, fc, h, cam, &tl->n_refl, &tl->n_shadow, &tl->n_tests, &tl->n_elided,
                                                  &defer);
     tl->n_hit += 1;
   }
@@ -254,7 +264,7 @@ __device__ __forceinline__ bool shade_sample(const ShadeConst& fc, const SceneDe
 
 // The lean lighting (see calculate_lighting) of a triangle hit in a scene without top-level triangle runs.
 // Returns true, with nothing counted or stored, if the sample needs the full instantiation.
-template <bool INERT>
+template <bool INERT, bool NEAREST>
 __device__ __forceinline__ bool shade_triangle_lean(const ShadeConst& fc, const SceneDev& sc, const TopTreeRef& tt, int s, d3 d,
                                                     int ti, double t_tri, double* rgb, ShadeTally* tl) {
   const d3 cam = rtx::ld3(fc.cam);
@@ -268,7 +278,7 @@ __device__ __forceinline__ bool shade_triangle_lean(const ShadeConst& fc, const 
   h.material = sc.tris[ti].material;
   h.id = ti;
   bool defer = false;
-  const RGBd c = calculate_lighting<true, false, true, INERT>(sc, tt, fc, h, cam, &tl->n_refl, &tl->n_shadow, &tl->n_tests, &tl->n_elided,
+  const RGBd c = calculate_lighting<true, false, true, INERT, NEAREST>(sc, tt, fc, h, cam, &tl->n_refl, &tl->n_shadow, &tl->n_tests, &tl->n_elided,
                                                        &defer);
   if (defer) return true;
   tl->n_hit += 1;
@@ -280,7 +290,7 @@ __device__ __forceinline__ bool shade_triangle_lean(const ShadeConst& fc, const 
 
 // HAS_TOP: the scene lists triangles at top level, so secondary rays scan them (the code of
 // that scan is left out of the instantiation for scenes without such runs).
-template <bool HAS_TOP>
+template <bool HAS_TOP, bool NEAREST = false>
 __global__ void __launch_bounds__(256)
 k_shade(ShadeConst fc, SceneDev sc, TopTreeArgs ta, const f2* __restrict__ trec, const float* __restrict__ gst2,
         const int* __restrict__ tslot_pos, const double* __restrict__ dirs,
@@ -296,7 +306,7 @@ k_shade(ShadeConst fc, SceneDev sc, TopTreeArgs ta, const f2* __restrict__ trec,
     // a triangle index or -2 - object index, both about to be used as such
     if (id >= 0) id = checked(id, sc.n_tris, cnt, 18);
     else id = -2 - checked(-2 - id, sc.n_objects, cnt, 19);
-    shade_sample<HAS_TOP>(fc, sc, tt, s, d, id, id >= 0 ? tval[s] : 0.0, rgb, &tl);
+    shade_sample<HAS_TOP, false, NEAREST>(fc, sc, tt, s, d, id, id >= 0 ? tval[s] : 0.0, rgb, &tl);
   }
   shade_tally_flush(cnt, tl);
 }
@@ -310,8 +320,8 @@ k_shade(ShadeConst fc, SceneDev sc, TopTreeArgs ta, const f2* __restrict__ trec,
 // Without top-level triangle runs the lean instantiation of the lighting runs here; the rare sample whose
 // reflected ray finds an object with a material goes to the shade queue (with its t), which k_shade serves
 // afterwards with the full instantiation.
-template <bool HAS_TOP, bool INERT = false>
-__global__ void __launch_bounds__(256, HAS_TOP ? 2 : (INERT ? SHADE_INERT_WAVES : SHADE_LEAN_WAVES))
+template <bool HAS_TOP, bool INERT = false, bool NEAREST = false>
+__global__ void __launch_bounds__(256, HAS_TOP ? (NEAREST ? 1 : 2) : (INERT ? SHADE_INERT_WAVES : SHADE_LEAN_WAVES))
 k_shade_candidates(ShadeConst fc, SceneDev sc, TopTreeArgs ta, const f2* __restrict__ trec, const float* __restrict__ gst2,
                    const int* __restrict__ tslot_pos, const SearchArgs* __restrict__ ap, double* rgb, int par) {
   DevCounters* cnt = (DevCounters*)as_global(ap->cnt);
@@ -359,9 +369,9 @@ k_shade_candidates(ShadeConst fc, SceneDev sc, TopTreeArgs ta, const f2* __restr
         hit_id[s] = ti;
       }
       if constexpr (HAS_TOP) {
-        if (want) shade_sample<true>(fc, sc, tt, s, d, ti, tv, rgb, &tl);
+        if (want) shade_sample<true, false, NEAREST>(fc, sc, tt, s, d, ti, tv, rgb, &tl);
       } else {
-        if (want) deferred = shade_triangle_lean<INERT>(fc, sc, tt, s, d, ti, tv, rgb, &tl);
+        if (want) deferred = shade_triangle_lean<INERT, NEAREST>(fc, sc, tt, s, d, ti, tv, rgb, &tl);
       }
       if constexpr (!HAS_TOP) {
         // samples that need the full lighting go to the shade queue, one atomic per wave and step; every

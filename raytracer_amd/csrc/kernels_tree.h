@@ -13,6 +13,16 @@
 // waves per SIMD (the walk is a chain of dependent scalar loads; occupancy hides their latency)
 // and runs the FP64 tests with all 64 lanes busy.
 constexpr int CAND_STAGE = 512;  // candidates a wave collects in LDS before it reserves global space
+// Nearest-hit policy: k_search_exact marks the candidates that are hits with this bit of their list position
+// (list positions stay below it: the host refuses larger groups) and lowers the ray's smallest parameter;
+// k_search_nearest then lets the marked candidates whose parameter IS that smallest one compete by position.
+constexpr int NEAR_MARK = 1 << 30;
+
+__device__ __forceinline__ unsigned long long f64_bits(double v) {
+  unsigned long long b;
+  __builtin_memcpy(&b, &v, 8);
+  return b;
+}
 
 // Evaluate one record of inner-node cones for the R rays of every lane; returns the mask of
 // children that some ray of the wave passes, or that are flagged "always descend".
@@ -89,9 +99,14 @@ k_search_tree(const SearchArgs* __restrict__ ap, const f2* __restrict__ rec, con
   search_prologue<R>(ap, base, nq, lane, sid, dx, dy, dz);
   {
     int* best_pos = ap->best_pos;  // this launch decides these rays: no hit so far
+    const bool nearest = ap->nearest != 0;
+    double* tval = ap->tval;  // nearest-hit policy: the smallest parameter so far, as an unsigned 64-bit minimum
 #pragma unroll
     for (int r = 0; r < R; ++r)
-      if (sid[r] >= 0) best_pos[sid[r]] = 0x7fffffff;
+      if (sid[r] >= 0) {
+        best_pos[sid[r]] = 0x7fffffff;
+        if (nearest) tval[sid[r]] = __builtin_inf();
+      }
   }
   unsigned n_leaf_rec = 0, n_node_rec = 0;
   int fill = 0;
@@ -212,6 +227,7 @@ k_search_tree(const SearchArgs* __restrict__ ap, const f2* __restrict__ rec, con
 // One lane per candidate: the reference's own arithmetic in FP64; a hit competes for the ray's
 // lowest list position.  Workgroup w serves candidate list w & 63 together with the other
 // workgroups of that residue (the grid is a multiple of 64 workgroups).
+template <bool NEAREST>
 __global__ void __launch_bounds__(256)
 k_search_exact(const SearchArgs* __restrict__ ap, int parity) {
   const DevCounters* cnt = ap->cnt;
@@ -220,11 +236,13 @@ k_search_exact(const SearchArgs* __restrict__ ap, int parity) {
     const int list = blockIdx.x & (NSLOT - 1), part = blockIdx.x / NSLOT, parts = gridDim.x / NSLOT;
     const int list_cap = ap->cand_cap / NSLOT;
     const int n = min(cnt->cand_n[parity][list][0], list_cap);
-    const auto* cand = as_global(ap->cand) + (size_t)list * list_cap;
+    auto* cand = as_global(ap->cand) + (size_t)list * list_cap;
     const auto* dirs = as_global(ap->dirs);
     const auto* tris = as_global(ap->tris);
     const auto* planes = as_global(ap->planes);
     auto* best_pos = as_global(ap->best_pos);
+    auto* tbits = as_global(reinterpret_cast<unsigned long long*>(ap->tval));
+    constexpr bool nearest = NEAREST;
     const d3 o = rtx::ld3(ap->cam);
     // The entry of the NEXT step is fetched (with the triangle index it leads to) before the
     // current one is evaluated: a step begins with a chain of dependent loads, and this way the
@@ -256,14 +274,53 @@ k_search_exact(const SearchArgs* __restrict__ ap, int parity) {
       double tv;
       n_exact += 1;
       if (rtx::tri_hit(rtx::mk(tv0[0], tv0[1], tv0[2]), rtx::mk(tv0[3], tv0[4], tv0[5]), rtx::mk(tv0[6], tv0[7], tv0[8]), pl, o,
-                       rtx::mk(dp[0], dp[1], dp[2]), &tv, &P))
-        atomicMin((int*)&best_pos[s], pos);
+                       rtx::mk(dp[0], dp[1], dp[2]), &tv, &P)) {
+        if (nearest) {  // t > 0: the bit patterns of positive doubles order like the values
+          atomicMin((unsigned long long*)&tbits[s], f64_bits(tv));
+          cand[i].y = pos | NEAR_MARK;
+        } else {
+          atomicMin((int*)&best_pos[s], pos);
+        }
+      }
       c = cn;
       ti = tin;
       i = inext;
     }
   }
   wave_count(ap->cnt, C_EXACT, (unsigned long long)n_exact);
+}
+
+// Nearest-hit policy, after k_search_exact: one lane per candidate; a marked candidate (a hit) whose parameter
+// equals the ray's smallest one competes for the ray with its list position (the first in list order among
+// equal parameters wins).  The parameter is evaluated again: the same two operations, the same value.
+__global__ void __launch_bounds__(256)
+k_search_nearest(const SearchArgs* __restrict__ ap, int parity) {
+  const DevCounters* cnt = ap->cnt;
+  if (cnt->overflow) return;
+  const int list = blockIdx.x & (NSLOT - 1), part = blockIdx.x / NSLOT, parts = gridDim.x / NSLOT;
+  const int list_cap = ap->cand_cap / NSLOT;
+  const int n = min(cnt->cand_n[parity][list][0], list_cap);
+  auto* cand = as_global(ap->cand) + (size_t)list * list_cap;
+  const auto* dirs = as_global(ap->dirs);
+  const auto* planes = as_global(ap->planes);
+  const auto* group = as_global(ap->group);
+  auto* best_pos = as_global(ap->best_pos);
+  const auto* tbits = as_global(reinterpret_cast<const unsigned long long*>(ap->tval));
+  const d3 o = rtx::ld3(ap->cam);
+  for (int i = part * blockDim.x + threadIdx.x; i < n; i += parts * blockDim.x) {
+    const int2 c = cand[i];
+    if (!(c.y & NEAR_MARK)) continue;
+    const int s = checked(c.x, ap->n_samples, ap->cnt, 21);
+    const int pos = checked(c.y & ~NEAR_MARK, ap->n_group, ap->cnt, 22);
+    cand[i].y = pos;
+    const int ti = checked(group[pos], ap->n_tris, ap->cnt, 23);
+    const auto* plp = planes + ti;
+    TriPlane pl;
+    pl.nx = plp->nx; pl.ny = plp->ny; pl.nz = plp->nz; pl.c = plp->c;
+    const auto* dp = dirs + (size_t)s * 3;
+    const double tv = rtx::tri_t(pl, o, rtx::mk(dp[0], dp[1], dp[2]));
+    if (f64_bits(tv) == tbits[s]) atomicMin((int*)&best_pos[s], pos);
+  }
 }
 
 // Top-level runs only (mode 1): one lane per ray of the queue, lowest list position that was

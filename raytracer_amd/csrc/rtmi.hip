@@ -743,10 +743,18 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
     g_last_error = "frames of more than 2^26 pixel blocks (about 4.3 gigapixels) are not supported";
     return RTMI_ERR_UNSUPPORTED;
   }
-  if (p->hit_policy != RTMI_HIT_LIST_ORDER) return RTMI_ERR_UNSUPPORTED;
+  if (p->hit_policy != RTMI_HIT_LIST_ORDER && p->hit_policy != RTMI_HIT_NEAREST) return RTMI_ERR_UNSUPPORTED;
   if (p->search != RTMI_SEARCH_CONE_TREE && p->search != RTMI_SEARCH_LIST_SCAN) return RTMI_ERR_INVALID_ARGUMENT;
   if (p->flags & ~RTMI_FLAG_NO_RAY_STATISTICS) return RTMI_ERR_INVALID_ARGUMENT;
   const bool use_tree = p->search == RTMI_SEARCH_CONE_TREE;
+  const bool nearest = p->hit_policy == RTMI_HIT_NEAREST;
+  if (nearest && !use_tree) {
+    g_last_error = "RTMI_HIT_NEAREST needs the cone tree search";
+    return RTMI_ERR_UNSUPPORTED;
+  }
+  if (nearest)
+    for (const TriGroup& g : sc->groups)
+      if (g.n >= NEAR_MARK) return RTMI_ERR_UNSUPPORTED;  // list positions share a word with the mark of a hit
   int spp = rtmi_samples_per_pixel(p->pixel_subdivision);
   if (spp < 0) return spp;
   int n1 = 1;
@@ -799,6 +807,7 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
     fc.ppw_h = (double)(p->width - 1) / sqrt(rtx::len_squared(rtx::sub(ur, ul)));
     fc.ppw_v = (double)(p->height - 1) / sqrt(rtx::len_squared(rtx::sub(ll, ul)));
   }
+  fc.nearest = nearest ? 1 : 0;
   fc.sub = p->pixel_subdivision;
   for (int a = 0; a < 3; ++a) fc.ambient[a] = p->ambient[a];
   fc.W = p->width; fc.H = p->height;
@@ -991,6 +1000,7 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
     a.n_tris = (int)sc->n_tris;
     a.n_records = (int)g.n_records;
     a.cand_cap = (int)std::min<size_t>(sc->wb.cap_cand, 0x7fffffff);
+    a.nearest = nearest ? 1 : 0;
     a.tree = g.tree;
   }
   if (sc->sargs_uploaded.size() != sc->h_sargs.size() ||
@@ -1032,7 +1042,7 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
     if (b0 > 0) HIP_TRY(hipMemsetAsync(&sc->wb.cnt->q_child, 0, sizeof(int) * 3, st));  // the first batch starts from the cleared counters
     int grid = (nsamples + 255) / 256;
     hipLaunchKernelGGL(k_gen, dim3((nsamples + 256 * GEN_ITERS - 1) / (256 * GEN_ITERS)), dim3(256), 0, st, fcb, sc->dev, d_blk, nsamples, sc->wb.hit_id, sc->wb.dirs, sc->wb.q_child,
-                       sc->wb.q_shade, sc->wb.q_top, sc->wb.cnt);
+                       sc->wb.q_shade, sc->wb.q_top, sc->wb.cnt, sc->wb.rgb);
     const int SR = search_rays_per_lane();
     const int search_grid = (nsamples + 256 * SR - 1) / (256 * SR);
     auto scan_kernel = SR == 8 ? k_search_primary<8> : (SR == 2 ? k_search_primary<2> : k_search_primary<4>);
@@ -1049,7 +1059,12 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
         launch_parity ^= 1;
         hipLaunchKernelGGL(tree_kernel, dim3(search_grid), dim3(256), 0, st, sc->d_sargs + gi, (const f2*)g.d_rec,
                            (const float*)g.d_tedge, (const int*)g.d_slot_pos, par);
-        hipLaunchKernelGGL(k_search_exact, dim3(sc->exact_grid), dim3(256), 0, st, sc->d_sargs + gi, par);
+        if (nearest) {
+          hipLaunchKernelGGL(k_search_exact<true>, dim3(sc->exact_grid), dim3(256), 0, st, sc->d_sargs + gi, par);
+          hipLaunchKernelGGL(k_search_nearest, dim3(sc->exact_grid), dim3(256), 0, st, sc->d_sargs + gi, par);
+        } else {
+          hipLaunchKernelGGL(k_search_exact<false>, dim3(sc->exact_grid), dim3(256), 0, st, sc->d_sargs + gi, par);
+        }
         HIP_TRY(hipEventRecord(ev[1], st));
         if (gi == 0)
           hipLaunchKernelGGL(k_search_finish, dim3(grid), dim3(256), 0, st, sc->d_sargs + gi, par);
@@ -1059,9 +1074,15 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
 #define RTMI_LAUNCH_SHADE_CANDIDATES(kernel)                                                                              \
   hipLaunchKernelGGL(kernel, dim3(sc->exact_grid), dim3(256), 0, st, shc, sc->dev, sc->top_args, (const f2*)sc->d_trec, \
                      (const float*)sc->d_gst2, (const int*)sc->groups[0].d_slot_pos, sc->d_sargs + gi, sc->wb.rgb, par)
-          if (has_top_runs) RTMI_LAUNCH_SHADE_CANDIDATES((k_shade_candidates<true, false>));
-          else if (inert) RTMI_LAUNCH_SHADE_CANDIDATES((k_shade_candidates<false, true>));
-          else RTMI_LAUNCH_SHADE_CANDIDATES((k_shade_candidates<false, false>));
+          if (nearest) {
+            if (has_top_runs) RTMI_LAUNCH_SHADE_CANDIDATES((k_shade_candidates<true, false, true>));
+            else if (inert) RTMI_LAUNCH_SHADE_CANDIDATES((k_shade_candidates<false, true, true>));
+            else RTMI_LAUNCH_SHADE_CANDIDATES((k_shade_candidates<false, false, true>));
+          } else {
+            if (has_top_runs) RTMI_LAUNCH_SHADE_CANDIDATES((k_shade_candidates<true, false>));
+            else if (inert) RTMI_LAUNCH_SHADE_CANDIDATES((k_shade_candidates<false, true>));
+            else RTMI_LAUNCH_SHADE_CANDIDATES((k_shade_candidates<false, false>));
+          }
 #undef RTMI_LAUNCH_SHADE_CANDIDATES
         }
       } else {
@@ -1075,7 +1096,8 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
     if (sc->groups[0].n > 0) {
       if ((rc = search_group(0))) return rc;
       hipLaunchKernelGGL(k_resolve_top, dim3(grid), dim3(256), 0, st, sc->dev, sc->wb.q_top, &sc->wb.cnt->q_top, sc->wb.tri_hit,
-                         sc->d_tri_owner, sc->wb.hit_id, sc->wb.q_child, sc->wb.q_shade, sc->wb.cnt);
+                         sc->d_tri_owner, sc->wb.hit_id, sc->wb.q_child, sc->wb.q_shade, sc->wb.cnt, (const double*)sc->wb.tval,
+                         (const double*)sc->wb.rgb, nearest ? 1 : 0);
     }
     for (size_t gi = 1; gi < sc->groups.size(); ++gi)
       if ((rc = search_group(gi))) return rc;
@@ -1084,9 +1106,18 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
     // nothing with a material that a reflected ray could find (k_shade_candidates queues those samples)
     if (!(use_tree && !has_top_runs && sc->n_plain_shadeable == 0 && !sc->lean_may_defer)) {
       if (b0 == 0) HIP_TRY(hipEventRecord(sc->ev_c, st));  // timed for the first batch only (frames are one batch as a rule)
-      hipLaunchKernelGGL(has_top_runs ? k_shade<true> : k_shade<false>, dim3(std::min(grid, 4 * sc->exact_grid)), dim3(256), 0, st, shc, sc->dev, sc->top_args, (const f2*)sc->d_trec,
-                         (const float*)sc->d_gst2, (const int*)sc->groups[0].d_slot_pos, sc->wb.dirs, sc->wb.tval, sc->wb.q_shade, &sc->wb.cnt->q_shade,
-                         sc->wb.hit_id, sc->wb.rgb, sc->wb.cnt);
+#define RTMI_LAUNCH_SHADE(kernel)                                                                                            \
+  hipLaunchKernelGGL(kernel, dim3(std::min(grid, 4 * sc->exact_grid)), dim3(256), 0, st, shc, sc->dev, sc->top_args,         \
+                     (const f2*)sc->d_trec, (const float*)sc->d_gst2, (const int*)sc->groups[0].d_slot_pos, sc->wb.dirs,     \
+                     sc->wb.tval, sc->wb.q_shade, &sc->wb.cnt->q_shade, sc->wb.hit_id, sc->wb.rgb, sc->wb.cnt)
+      if (nearest) {
+        if (has_top_runs) RTMI_LAUNCH_SHADE((k_shade<true, true>));
+        else RTMI_LAUNCH_SHADE((k_shade<false, true>));
+      } else {
+        if (has_top_runs) RTMI_LAUNCH_SHADE((k_shade<true, false>));
+        else RTMI_LAUNCH_SHADE((k_shade<false, false>));
+      }
+#undef RTMI_LAUNCH_SHADE
       if (b0 == 0) HIP_TRY(hipEventRecord(sc->ev_d, st));
       shade_queue_launched = true;
     }
@@ -1128,6 +1159,10 @@ static int32_t render_finish(rtmi_scene* sc, rtmi_counters* counters) {
     // More candidate pairs than the list holds (rays that pass very many triangle cones, e.g. deep
     // stacks of overlapping triangles): the frame is rendered again with the list scan, which
     // needs no such list and gives the same image.
+    if (sc->pend_params.hit_policy == RTMI_HIT_NEAREST) {
+      g_last_error = "the frame has more candidate pairs than the lists hold, and RTMI_HIT_NEAREST has no list-scan fallback";
+      return RTMI_ERR_UNSUPPORTED;
+    }
     rtmi_params p2 = sc->pend_params;
     p2.search = RTMI_SEARCH_LIST_SCAN;
     const rtmi_camera cam2 = sc->pend_cam;

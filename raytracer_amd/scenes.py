@@ -71,12 +71,13 @@ def make_camera(pos, direction, focal_length) -> _abi.Camera:
 
 
 def make_params(width, height, subdivision=1.0, ambient=(0.2, 0.2, 0.2), window=None,
-                tile_size=0, tile_rank=0, tile_world=1, search=_abi.RTMI_SEARCH_CONE_TREE, flags=0) -> _abi.Params:
+                tile_size=0, tile_rank=0, tile_world=1, search=_abi.RTMI_SEARCH_CONE_TREE, flags=0,
+                hit_policy=_abi.RTMI_HIT_LIST_ORDER) -> _abi.Params:
     p = _abi.Params()
     p.width, p.height = int(width), int(height)
     p.pixel_subdivision = float(subdivision)
     p.ambient[:] = [float(x) for x in ambient]
-    p.hit_policy = _abi.RTMI_HIT_LIST_ORDER
+    p.hit_policy = int(hit_policy)
     if window is not None:
         p.x0, p.y0, p.x1, p.y1 = [int(x) for x in window]
     p.tile_size, p.tile_rank, p.tile_world = int(tile_size), int(tile_rank), int(tile_world)

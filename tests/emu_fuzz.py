@@ -21,7 +21,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 
 import emu_util  # noqa: E402
-from raytracer_amd import scenes  # noqa: E402
+from raytracer_amd import _abi, scenes  # noqa: E402
 
 GROUP_SIZES = (0, 1, 2, 7, 8, 9, 15, 16, 17, 63, 64, 65, 100, 260, 520)
 SUBDIVISIONS = (1.0, 1.0, 0.5, 0.5, 0.25, 0.4, 0.3, 0.7, 0.15)
@@ -109,6 +109,10 @@ def random_case(seed, index):
 def run_one(seed, index, oracle, keep_dir=None, tsan=False):
     from test_emulated_kernels import SEARCHES, check_frames
     data, cam, params = random_case(seed, index)
+    # every third case under the nearest-hit extension (cone tree only, no list-scan fallback after an overflow)
+    nearest = index % 3 == 2 and index % 5 != 4
+    if nearest:
+        params.hit_policy = _abi.RTMI_HIT_NEAREST
     expected = [oracle.render(data, cam, params, threads=1)] * 2
     env = {"EMU_SEED": str(index % 4), "EMU_FILL": str([0xA5, 0, 0xFF, 0x7F][index % 4]), "EMU_CUS": str(1 + index % 3)}
     if index % 5 == 4:  # candidate lists that overflow, frames cut into batches
@@ -116,6 +120,8 @@ def run_one(seed, index, oracle, keep_dir=None, tsan=False):
     if index % 7 == 6:
         env["RTMI_MAX_BATCH_SAMPLES"] = "1024"
     for name, search in SEARCHES.items():
+        if nearest and name != "tree":
+            continue
         p = copy.copy(params)
         p.search = search
         with tempfile.TemporaryDirectory(dir=keep_dir) as d:

@@ -21,16 +21,21 @@ from raytracer_amd import scenes  # noqa: E402
 OUT = os.path.dirname(os.path.abspath(__file__))
 
 
-def save(name, data, cam_kw, W, H, sub, ambient=(0.2, 0.2, 0.2)):
+ONLY = sys.argv[1:]  # fixture names to (re)generate; none = all
+
+
+def save(name, data, cam_kw, W, H, sub, ambient=(0.2, 0.2, 0.2), hit_policy=0):
+    if ONLY and name not in ONLY:
+        return
     cam = scenes.make_camera(**cam_kw)
-    params = scenes.make_params(W, H, sub, ambient)
+    params = scenes.make_params(W, H, sub, ambient, hit_policy=hit_policy)
     rgba, hit, cnt = oracle.render(data, cam, params)
     arrs = data.to_arrays()
     np.savez_compressed(
         os.path.join(OUT, name + ".npz"),
         cam=np.array(list(cam_kw["pos"]) + list(cam_kw["direction"]) + [cam_kw["focal_length"]], np.float64),
         params=np.array([W, H, sub] + list(ambient), np.float64),
-        rgba=rgba, hit=hit,
+        rgba=rgba, hit=hit, hit_policy=np.array([hit_policy], np.int64),
         counters=np.array([cnt[k] for k in ("samples", "rays_reflection", "rays_shadow", "tri_tests",
                                             "sphere_tests", "primary_hits")], np.int64),
         **arrs)
@@ -86,6 +91,12 @@ def main():
     save("ico2_toplevel_3L_40x40", scenes.mesh_scene(2, "T", 3), scenes.MESH_CAMERA, 40, 40, 0.5)
     save("mixed_3L_64x48", mixed_scene(), dict(pos=(0.5, 0.8, 5.0), direction=(-0.05, -0.12, -1.0), focal_length=8.0),
          64, 48, 0.5, ambient=(0.25, 0.2, 0.3))
+    # the nearest-hit extension (RTMI_HIT_NEAREST), on scenes where it differs from the reference's list order:
+    # a non-convex mesh whose triangles are listed in shuffled order, and the mixed scene
+    save("ico2_bounded_nearest_48x40", scenes.mesh_scene(2, "B", 2, shuffle_seed=11, bounding_sphere=oracle.bounding_sphere),
+         scenes.MESH_CAMERA, 48, 40, 0.5, hit_policy=1)
+    save("mixed_nearest_3L_64x48", mixed_scene(), dict(pos=(0.5, 0.8, 5.0), direction=(-0.05, -0.12, -1.0), focal_length=8.0),
+         64, 48, 0.5, ambient=(0.25, 0.2, 0.3), hit_policy=1)
 
 
 if __name__ == "__main__":

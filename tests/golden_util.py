@@ -25,6 +25,7 @@ def load_golden(name):
     c = z["cam"]
     cam = scenes.make_camera(c[0:3], c[3:6], c[6])
     p = z["params"]
-    params = scenes.make_params(int(p[0]), int(p[1]), float(p[2]), tuple(p[3:6]))
+    policy = int(z["hit_policy"][0]) if "hit_policy" in z.files else 0  # 1: the nearest-hit extension
+    params = scenes.make_params(int(p[0]), int(p[1]), float(p[2]), tuple(p[3:6]), hit_policy=policy)
     counters = dict(zip(COUNTER_KEYS, (int(x) for x in z["counters"])))
     return data, cam, params, z["rgba"], z["hit"], counters

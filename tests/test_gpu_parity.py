@@ -569,3 +569,37 @@ def test_pixels_only_flag_gives_the_same_frame_without_secondary_rays(oracle_mod
         sc.close()
     with pytest.raises(rt.RtmiError):
         rt.Scene(scenes.two_sphere_scene()).render(scenes.make_camera(**scenes.VC_CAMERA), scenes.make_params(32, 32, flags=6))
+
+
+def test_nearest_hit_extension(oracle_mod, rt):
+    """RTMI_HIT_NEAREST (an extension, not the reference's behaviour): the hit with the smallest parameter instead of
+    the first in list order, at the primary ray, inside a bounding sphere and for the reflection ray.  Bit-exact
+    against the oracle's implementation of the same rule on scenes where the two policies differ."""
+    cam = scenes.make_camera(**scenes.MESH_CAMERA)
+    rng = np.random.default_rng(5)
+    soup = random_soup(rng, 400, 0.5)
+    c, r = rt.bounding_sphere(soup[:250])
+    mixed = scenes.SceneData(lights=three_lights(), materials=TWO_MATS, triangles=soup,
+                             objects=np.concatenate([scenes.sphere_object((0.8, 0.5, 0.6), 0.7, 1), scenes.light_object(1),
+                                                     scenes.sphere_object(c, r, -1, bounding=True, first=0, count=250),
+                                                     scenes.triangles_object(250, 150), scenes.sphere_object((-1.2, -0.4, 0.3), 0.6, 0)]))
+    cases = [(scenes.mesh_scene(3, "B", 3, shuffle_seed=1, bounding_sphere=rt.bounding_sphere), cam, (200, 160, 0.5)),
+             (scenes.mesh_scene(3, "T", 3, shuffle_seed=2), scenes.make_camera((0.6, 0.4, 3.5), (-0.15, -0.1, -1.0), 8.0), (120, 100, 0.5)),
+             (mixed, scenes.make_camera((0.3, -0.2, 7.0), (0.02, 0.03, -1.0), 9.0), (128, 96, 0.25)),
+             (scenes.two_sphere_scene(), scenes.make_camera((60.0, 10.0, 40.0), (-1.0, -0.2, -0.6), 2.0), (160, 120, 1.0))]
+    differs = 0
+    for data, c_, (W, H, sub) in cases:
+        p = scenes.make_params(W, H, sub, hit_policy=_abi.RTMI_HIT_NEAREST)
+        o_rgba, o_hit, o_cnt = oracle_mod.render(data, c_, p, threads=16)
+        sc = rt.Scene(data)
+        g_rgba, g_hit, g_cnt = sc.render(c_, p)
+        assert (g_hit == o_hit).all(), f"{int((g_hit != o_hit).sum())} hit-id mismatches of {o_hit.size}"
+        assert (g_rgba == o_rgba).all()
+        for k in ("samples", "rays_reflection", "rays_shadow", "primary_hits"):
+            assert g_cnt[k] == o_cnt[k], k
+        l_rgba, l_hit, _ = sc.render(c_, scenes.make_params(W, H, sub))
+        differs += int((l_hit != g_hit).sum())
+        with pytest.raises(rt.RtmiError):  # no list-scan form of the extension
+            sc.render(c_, scenes.make_params(W, H, sub, hit_policy=_abi.RTMI_HIT_NEAREST, search=_abi.RTMI_SEARCH_LIST_SCAN))
+        sc.close()
+    assert differs > 1000

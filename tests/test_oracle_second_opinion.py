@@ -94,3 +94,22 @@ def test_second_restatement_agrees_on_generated_scenes(oracle_mod):
         agree(oracle_mod, data, cam, p)
         done += 1
     assert done >= 20
+
+
+def test_second_restatement_agrees_on_the_nearest_hit_extension(oracle_mod):
+    """RTMI_HIT_NEAREST in the C oracle against `min(intersections, key=parameter)` in the Python restatement, on
+    scenes where the two policies differ: a non-convex bounded mesh, overlapping spheres, top-level triangles."""
+    from raytracer_amd import _abi
+    data, cam, params, _, _, _ = load_golden("mixed_3L_64x48")
+    differs = 0
+    for d, c, size in ((data, cam, (22, 16, 0.5)),
+                       (scenes.mesh_scene(1, "B", 2, bounding_sphere=oracle_mod.bounding_sphere, shuffle_seed=5),
+                        scenes.make_camera(**scenes.MESH_CAMERA), (14, 12, 0.5)),
+                       (scenes.mesh_scene(1, "T", 3, shuffle_seed=6), scenes.make_camera((0.6, 0.4, 3.5), (-0.15, -0.1, -1.0), 8.0), (12, 12, 1.0)),
+                       (scenes.two_sphere_scene(), scenes.make_camera((60.0, 10.0, 40.0), (-1.0, -0.2, -0.6), 2.0), (20, 16, 1.0))):
+        p = scenes.make_params(size[0], size[1], size[2], hit_policy=_abi.RTMI_HIT_NEAREST)
+        agree(oracle_mod, d, c, p)
+        a = oracle_mod.render(d, c, p)[1]
+        b = oracle_mod.render(d, c, scenes.make_params(size[0], size[1], size[2]))[1]
+        differs += int((a != b).sum())
+    assert differs > 0  # the extension does change hits on these scenes
