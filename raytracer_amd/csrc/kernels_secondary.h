@@ -82,7 +82,7 @@ __device__ inline TopTreeRef make_top_tree(const TopTreeArgs& a, const f2* rec, 
 // A general-origin ray (reflection or shadow ray) against ALL top-level triangles: the ordinal of
 // the hit that comes first in list order (any_only: of some hit), or -1.  The lanes that call this
 // together walk the tree together, like k_search_tree: a record of eight bounding spheres is
-// evaluated for every calling lane's own ray (packed line-sphere test, two spheres per
+// evaluated for every calling lane's own ray (packed half-line-sphere test, two spheres per
 // instruction), and a child is entered if some lane passes.  At a leaf the per-triangle cascade
 // of k_pack_general follows, then rtx::tri_hit in FP64.  Called from divergent shading code: the
 // wave-level votes only see the lanes that are tracing.
@@ -104,6 +104,12 @@ __device__ inline int top_tree_trace(const SceneDev& sc, const TopTreeRef& T, d3
     const f2 cx = rp[pr * 4 + 0], cy = rp[pr * 4 + 1], cz = rp[pr * 4 + 2], nk = rp[pr * 4 + 3];
     f2 A = __builtin_elementwise_fma(cz, Z, __builtin_elementwise_fma(cy, Y, __builtin_elementwise_fma(cx, X, N0)));
     f2 B = __builtin_elementwise_fma(cz, OZ, __builtin_elementwise_fma(cy, OY, __builtin_elementwise_fma(cx, OX, N1)));
+    // A is the parameter of the line's closest approach to the centre.  A triangle is only hit at a positive
+    // parameter (REN:152), and when the closest approach lies behind the origin every point ahead is farther from
+    // the centre than the origin is: then the sphere can only hold a hit if it holds the origin, B + nk >= 0.
+    // (A wrongly rounded to below zero is smaller than the margin in nk squared away.)
+    A.x = __builtin_fmaxf(A.x, 0.0f);
+    A.y = __builtin_fmaxf(A.y, 0.0f);
     return __builtin_elementwise_fma(A, A, B) + nk;
   };
   auto level_off = [&](int lvl) {
@@ -274,7 +280,7 @@ __device__ inline bool trace_top_secondary(const SceneDev& sc, const TopTreeRef&
 // A general-origin ray (reflection or shadow ray) against ALL top-level triangles: the ordinal of
 // the hit that comes first in list order (any_only: of some hit), or -1.  The lanes that call this
 // together walk the tree together, like k_search_tree: a record of eight bounding spheres is
-// evaluated for every calling lane's own ray (packed line-sphere test, two spheres per
+// evaluated for every calling lane's own ray (packed half-line-sphere test, two spheres per
 // instruction), and a child is entered if some lane passes.  At a leaf the per-triangle cascade
 // of k_pack_general follows, then rtx::tri_hit in FP64.  Called from divergent shading code: the
 // wave-level votes only see the lanes that are tracing.
@@ -298,6 +304,12 @@ __device__ inline int top_tree_trace_nearest(const SceneDev& sc, const TopTreeRe
     const f2 cx = rp[pr * 4 + 0], cy = rp[pr * 4 + 1], cz = rp[pr * 4 + 2], nk = rp[pr * 4 + 3];
     f2 A = __builtin_elementwise_fma(cz, Z, __builtin_elementwise_fma(cy, Y, __builtin_elementwise_fma(cx, X, N0)));
     f2 B = __builtin_elementwise_fma(cz, OZ, __builtin_elementwise_fma(cy, OY, __builtin_elementwise_fma(cx, OX, N1)));
+    // A is the parameter of the line's closest approach to the centre.  A triangle is only hit at a positive
+    // parameter (REN:152), and when the closest approach lies behind the origin every point ahead is farther from
+    // the centre than the origin is: then the sphere can only hold a hit if it holds the origin, B + nk >= 0.
+    // (A wrongly rounded to below zero is smaller than the margin in nk squared away.)
+    A.x = __builtin_fmaxf(A.x, 0.0f);
+    A.y = __builtin_fmaxf(A.y, 0.0f);
     return __builtin_elementwise_fma(A, A, B) + nk;
   };
   auto level_off = [&](int lvl) {

@@ -12,6 +12,10 @@ constexpr int SHADE_LEAN_WAVES = RTMI_SHADE_LEAN_WAVES;  // resident waves per S
 #define RTMI_SHADE_INERT_WAVES 5
 #endif
 constexpr int SHADE_INERT_WAVES = RTMI_SHADE_INERT_WAVES;
+#ifndef RTMI_TRACE_TOP_WAVES
+#define RTMI_TRACE_TOP_WAVES 4
+#endif
+constexpr int TRACE_TOP_WAVES = RTMI_TRACE_TOP_WAVES;  // resident waves per SIMD k_trace_top is compiled for
 
 struct RGBd {
   double r, g, b;
@@ -76,6 +80,75 @@ __device__ __forceinline__ bool trace_secondary(const SceneDev& sc, const TopTre
   else return trace_top_secondary<HAS_TOP>(sc, tt, o, d, want_first, h, any_non_bounding, n_tests);
 }
 
+// The secondary rays of one sample can be traced in one kernel and their outcomes used by another: the tracing
+// kernel wants as many resident waves as it can get (a tree walk is a chain of dependent loads), the lighting
+// arithmetic wants registers.  TRACE_LIVE traces where the lighting needs the outcome (one kernel does both);
+// TRACE_RECORD traces and notes the outcomes in a TraceRec, in the order the lighting asks for them;
+// TRACE_REPLAY takes them from the TraceRec instead of tracing.  Both kernels run the same lighting code on the
+// same operands, so they ask for the same rays in the same order.
+enum { TRACE_LIVE = 0, TRACE_RECORD = 1, TRACE_REPLAY = 2 };
+struct TraceRec {
+  int id;         // the reflection ray's intersection: triangle index, -2 - object index, or -1 for none
+  double t;       // its parameter
+  unsigned bits;  // one bit per shadow ray, in the order they are traced: something other than a bounding sphere was hit
+  int nbits;
+};
+
+// The reflection ray (RTF:212-216): its first intersection under the frame's hit policy.
+template <int MODE, bool HAS_TOP, bool NEAREST>
+__device__ __forceinline__ bool traced_first(const SceneDev& sc, const TopTreeRef& tt, d3 o, d3 d, Hit* h, tally_t* n_tests,
+                                             TraceRec* rec) {
+  if constexpr (MODE == TRACE_REPLAY) {
+    const int id = rec->id;
+    if (id == -1) return false;
+    // the intersection as the tracing functions build it: point = origin + parameter * direction
+    h->id = id;
+    h->t = rec->t;
+    h->P = rtx::add(o, rtx::smul(rec->t, d));
+    if (id >= 0) {
+      const TriPlane pl = sc.planes[id];
+      h->n = rtx::mk(pl.nx, pl.ny, pl.nz); h->has_normal = 1; h->n_unit = 1; h->material = sc.tris[id].material;
+    } else {
+      const rtmi_object& ob = sc.objects[-2 - id];
+      if (ob.kind == RTMI_LIGHT) {
+        h->has_normal = 0; h->n_unit = 1; h->material = -1;
+      } else {
+        const d3 raw = rtx::sub(h->P, rtx::ld3(ob.center));
+        h->n_unit = ob.material >= 0;
+        h->n = h->n_unit ? rtx::normalize(raw) : raw; h->has_normal = 1; h->material = ob.material;
+      }
+    }
+    return true;
+  } else {
+    bool anb;
+    const bool found = trace_secondary<HAS_TOP, NEAREST>(sc, tt, o, d, true, h, &anb, n_tests);
+    if constexpr (MODE == TRACE_RECORD) {
+      rec->id = found ? h->id : -1;
+      rec->t = found ? h->t : 0.0;
+    }
+    return found;
+  }
+}
+
+// A shadow ray (RTF:236-243): does it hit anything other than a bounding sphere.
+template <int MODE, bool HAS_TOP, bool NEAREST>
+__device__ __forceinline__ bool traced_any(const SceneDev& sc, const TopTreeRef& tt, d3 o, d3 d, tally_t* n_tests, TraceRec* rec) {
+  if constexpr (MODE == TRACE_REPLAY) {
+    const bool anb = (rec->bits >> (rec->nbits & 31)) & 1u;
+    rec->nbits += 1;
+    return anb;
+  } else {
+    Hit dummy;
+    bool anb = false;
+    trace_secondary<HAS_TOP, NEAREST>(sc, tt, o, d, false, &dummy, &anb, n_tests);
+    if constexpr (MODE == TRACE_RECORD) {
+      rec->bits |= (anb ? 1u : 0u) << (rec->nbits & 31);
+      rec->nbits += 1;
+    }
+    return anb;
+  }
+}
+
 // LEAN (with REFLECT only): the instantiation for the common case that (1) the reflected ray finds nothing
 // whose lighting has to be evaluated -- no hit, a light, or an object without a material, whose contribution
 // is exactly zero (RTF:192, :245) -- and (2) the specular exponent is a small whole number.  It leaves the
@@ -87,9 +160,10 @@ __device__ __forceinline__ bool trace_secondary(const SceneDev& sc, const TopTre
 // changes a pixel -- a bounding sphere blocks no light (RTF:241) and, lacking a material, reflects none
 // (RTF:192, :245) -- so the rays are neither traced nor counted (the caller asked for pixels, not for the
 // reference's ray statistics: RTMI_FLAG_NO_RAY_STATISTICS).
-template <bool REFLECT, bool HAS_TOP, bool LEAN = false, bool INERT = false, bool NEAREST = false>
+template <bool REFLECT, bool HAS_TOP, bool LEAN = false, bool INERT = false, bool NEAREST = false, int MODE = TRACE_LIVE>
 __device__ __forceinline__ RGBd calculate_lighting(const SceneDev& sc, const TopTreeRef& tt, const ShadeConst& fc, const Hit& is, d3 camera,
-                                   tally_t* n_refl, tally_t* n_shadow, tally_t* n_tests, tally_t* n_elided, bool* defer = nullptr) {
+                                   tally_t* n_refl, tally_t* n_shadow, tally_t* n_tests, tally_t* n_elided, bool* defer = nullptr,
+                                   TraceRec* rec = nullptr) {
   d3 surface_point = is.P;
   RGBd I = {0.0, 0.0, 0.0};
   const bool has_material = is.material >= 0;
@@ -145,9 +219,9 @@ __device__ __forceinline__ RGBd calculate_lighting(const SceneDev& sc, const Top
       *n_tests += nt;
     } else {
       *n_refl += 1;
-      if (trace_secondary<HAS_TOP, NEAREST>(sc, tt, surface_point, reflection, true, &rh, &anb, n_tests)) {
-        contribution = calculate_lighting<false, HAS_TOP, false, false, NEAREST>(sc, tt, fc, rh, surface_point, n_refl, n_shadow, n_tests,
-                                                                                 n_elided);
+      if (traced_first<MODE, HAS_TOP, NEAREST>(sc, tt, surface_point, reflection, &rh, n_tests, rec)) {
+        contribution = calculate_lighting<false, HAS_TOP, false, false, NEAREST, MODE>(sc, tt, fc, rh, surface_point, n_refl, n_shadow,
+                                                                                       n_tests, n_elided, nullptr, rec);
       }
     }
     I.r = I.r + contribution.r;
@@ -173,11 +247,8 @@ __device__ __forceinline__ RGBd calculate_lighting(const SceneDev& sc, const Top
     double ndl = rtx::dp(point_to_light, normal);
     if (ndl <= 0) continue;
     if constexpr (!INERT) {
-      Hit dummy;
-      bool anb = false;
       *n_shadow += 1;
-      trace_secondary<HAS_TOP, NEAREST>(sc, tt, surface_point, point_to_light, false, &dummy, &anb, n_tests);
-      if (anb) continue;           // RTF:241
+      if (traced_any<MODE, HAS_TOP, NEAREST>(sc, tt, surface_point, point_to_light, n_tests, rec)) continue;  // RTF:241
     }
     if (!has_material) continue; // RTF:245
     double lr = light.diffuse[0], lg = light.diffuse[1], lb = light.diffuse[2];
@@ -214,9 +285,10 @@ __device__ inline void shade_tally_flush(DevCounters* cnt, const ShadeTally& t) 
 // Shade sample s whose primary ray (direction d) hit `id` (triangle index, or -2 - object index);
 // t_tri is the triangle's intersection parameter.  LEAN: returns true, with nothing counted or stored,
 // if the sample needs the full instantiation (see calculate_lighting).
-template <bool HAS_TOP, bool LEAN = false, bool NEAREST = false>
+// MODE (see TraceRec): TRACE_RECORD traces the sample's secondary rays into *rec and stores no colour.
+template <bool HAS_TOP, bool LEAN = false, bool NEAREST = false, int MODE = TRACE_LIVE>
 __device__ __forceinline__ bool shade_sample(const ShadeConst& fc, const SceneDev& sc, const TopTreeRef& tt, int s, d3 d,
-                                             int id, double t_tri, double* rgb, ShadeTally* tl) {
+                                             int id, double t_tri, double* rgb, ShadeTally* tl, TraceRec* rec = nullptr) {
   d3 cam = rtx::ld3(fc.cam);
   Hit h;
   bool ok = false;
@@ -252,13 +324,15 @@ __device__ __forceinline__ bool shade_sample(const ShadeConst& fc, const SceneDe
   if (ok) {
     bool defer = false;
     static_assert(!LEAN, "the lean lighting needs a wave-uniform material: shade_triangle_lean");
-    c = calculate_lighting<true, HAS_TOP, false, false, NEAREST>(sc, tt, fc, h, cam, &tl->n_refl, &tl->n_shadow, &tl->n_tests, &tl->n_elided,
-                                                 &defer);
+    c = calculate_lighting<true, HAS_TOP, false, false, NEAREST, MODE>(sc, tt, fc, h, cam, &tl->n_refl, &tl->n_shadow, &tl->n_tests,
+                                                                       &tl->n_elided, &defer, rec);
     tl->n_hit += 1;
   }
-  rgb[(size_t)s * 3 + 0] = c.r;
-  rgb[(size_t)s * 3 + 1] = c.g;
-  rgb[(size_t)s * 3 + 2] = c.b;
+  if constexpr (MODE != TRACE_RECORD) {
+    rgb[(size_t)s * 3 + 0] = c.r;
+    rgb[(size_t)s * 3 + 1] = c.g;
+    rgb[(size_t)s * 3 + 2] = c.b;
+  }
   return false;
 }
 
@@ -307,6 +381,69 @@ k_shade(ShadeConst fc, SceneDev sc, TopTreeArgs ta, const f2* __restrict__ trec,
     if (id >= 0) id = checked(id, sc.n_tris, cnt, 18);
     else id = -2 - checked(-2 - id, sc.n_objects, cnt, 19);
     shade_sample<HAS_TOP, false, NEAREST>(fc, sc, tt, s, d, id, id >= 0 ? tval[s] : 0.0, rgb, &tl);
+  }
+  shade_tally_flush(cnt, tl);
+}
+
+// Scenes with top-level triangle runs shade their queued hits in two launches.  k_trace_top traces every secondary
+// ray of a hit -- the reflection ray, the shadow rays of the reflected hit, the shadow rays of the hit itself,
+// each a walk of the bounding-sphere tree -- and keeps only the outcomes: the reflected intersection (rec_id per
+// queue entry, its parameter in the sample's second colour slot) and one bit per shadow ray (rec_bits per queue
+// entry).  Without the colour arithmetic it needs half the registers of k_shade<true>, so twice the waves hide
+// the latency of the walks.  k_shade_replay then evaluates the lighting from the recorded outcomes without
+// tracing anything.  The ray counters are kept by k_trace_top, the hit counter by k_shade_replay.
+template <bool NEAREST>
+__global__ void __launch_bounds__(256, TRACE_TOP_WAVES)
+k_trace_top(ShadeConst fc, SceneDev sc, TopTreeArgs ta, const f2* __restrict__ trec, const float* __restrict__ gst2,
+            const int* __restrict__ tslot_pos, const double* __restrict__ dirs, const double* __restrict__ tval,
+            const int* __restrict__ q_shade, const int* __restrict__ nq_ptr, const int* __restrict__ hit_id, double* rgb,
+            DevCounters* cnt, int* rec_id, unsigned* rec_bits) {
+  const TopTreeRef tt = make_top_tree(ta, trec, gst2, tslot_pos);
+  ShadeTally tl;
+  const int nq = *nq_ptr;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
+    int s = checked(q_shade[q], sc.n_samples, cnt, 24);
+    d3 d = rtx::mk(dirs[(size_t)s * 3 + 0], dirs[(size_t)s * 3 + 1], dirs[(size_t)s * 3 + 2]);
+    int id = hit_id[s];
+    if (id >= 0) id = checked(id, sc.n_tris, cnt, 25);
+    else id = -2 - checked(-2 - id, sc.n_objects, cnt, 26);
+    TraceRec rec;
+    rec.id = -1; rec.t = 0.0; rec.bits = 0u; rec.nbits = 0;
+    shade_sample<true, false, NEAREST, TRACE_RECORD>(fc, sc, tt, s, d, id, id >= 0 ? tval[s] : 0.0, rgb, &tl, &rec);
+    rec_id[q] = rec.id;
+    rec_bits[q] = rec.bits;
+    rgb[(size_t)s * 3 + 1] = rec.t;
+  }
+  tl.n_hit = 0;  // counted by k_shade_replay
+  shade_tally_flush(cnt, tl);
+}
+
+template <bool NEAREST>
+__global__ void __launch_bounds__(256)
+k_shade_replay(ShadeConst fc, SceneDev sc, TopTreeArgs ta, const f2* __restrict__ trec, const float* __restrict__ gst2,
+               const int* __restrict__ tslot_pos, const double* __restrict__ dirs, const double* __restrict__ tval,
+               const int* __restrict__ q_shade, const int* __restrict__ nq_ptr, const int* __restrict__ hit_id, double* rgb,
+               DevCounters* cnt, const int* __restrict__ rec_id, const unsigned* __restrict__ rec_bits) {
+  const TopTreeRef tt = make_top_tree(ta, trec, gst2, tslot_pos);
+  ShadeTally tl;
+  const int nq = *nq_ptr;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
+    int s = checked(q_shade[q], sc.n_samples, cnt, 27);
+    d3 d = rtx::mk(dirs[(size_t)s * 3 + 0], dirs[(size_t)s * 3 + 1], dirs[(size_t)s * 3 + 2]);
+    int id = hit_id[s];
+    if (id >= 0) id = checked(id, sc.n_tris, cnt, 28);
+    else id = -2 - checked(-2 - id, sc.n_objects, cnt, 29);
+    TraceRec rec;
+    rec.id = rec_id[q];
+    // a recorded intersection is about to be used as an index
+    if (rec.id >= 0) rec.id = checked(rec.id, sc.n_tris, cnt, 30);
+    else if (rec.id <= -2) rec.id = -2 - checked(-2 - rec.id, sc.n_objects, cnt, 31);
+    rec.t = rgb[(size_t)s * 3 + 1];
+    rec.bits = rec_bits[q];
+    rec.nbits = 0;
+    ShadeTally rays;  // the rays were counted when they were traced
+    shade_sample<true, false, NEAREST, TRACE_REPLAY>(fc, sc, tt, s, d, id, id >= 0 ? tval[s] : 0.0, rgb, &rays, &rec);
+    tl.n_hit += rays.n_hit;
   }
   shade_tally_flush(cnt, tl);
 }

@@ -717,6 +717,15 @@ static int search_rays_per_lane() {
   }();
   return r;
 }
+// Scenes with top-level triangle runs: trace the queued hits' secondary rays in one kernel and shade from the
+// recorded outcomes in another (the default), or do both in one kernel (RTMI_TRACE_THEN_SHADE=0, for comparison).
+static bool trace_then_shade() {
+  static bool v = [] {
+    const char* e = getenv("RTMI_TRACE_THEN_SHADE");
+    return !(e && atoi(e) == 0);
+  }();
+  return v;
+}
 constexpr int MAX_FRAME_EDGE = 1 << 20;          // widest and tallest frame accepted, in pixels
 constexpr int64_t MAX_FRAME_BLOCKS = 1ll << 26;  // 8x8 pixel blocks of a frame (the host keeps a list of them)
 constexpr size_t MAX_BATCH_SAMPLES = 1u << 28;  // 256 Mi samples per batch (about 100 B of work buffers per sample)
@@ -1110,13 +1119,29 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
   hipLaunchKernelGGL(kernel, dim3(std::min(grid, 4 * sc->exact_grid)), dim3(256), 0, st, shc, sc->dev, sc->top_args,         \
                      (const f2*)sc->d_trec, (const float*)sc->d_gst2, (const int*)sc->groups[0].d_slot_pos, sc->wb.dirs,     \
                      sc->wb.tval, sc->wb.q_shade, &sc->wb.cnt->q_shade, sc->wb.hit_id, sc->wb.rgb, sc->wb.cnt)
-      if (nearest) {
+#define RTMI_LAUNCH_TRACE_REPLAY(NEAREST)                                                                                    \
+  do {                                                                                                                      \
+    /* tri_hit and q_top are free once k_resolve_top has run: they carry the recorded outcomes */                           \
+    hipLaunchKernelGGL((k_trace_top<NEAREST>), dim3(std::min(grid, 4 * sc->exact_grid)), dim3(256), 0, st, shc, sc->dev,    \
+                       sc->top_args, (const f2*)sc->d_trec, (const float*)sc->d_gst2, (const int*)sc->groups[0].d_slot_pos, \
+                       sc->wb.dirs, sc->wb.tval, sc->wb.q_shade, &sc->wb.cnt->q_shade, sc->wb.hit_id, sc->wb.rgb,           \
+                       sc->wb.cnt, sc->wb.tri_hit, (unsigned*)sc->wb.q_top);                                                \
+    hipLaunchKernelGGL((k_shade_replay<NEAREST>), dim3(std::min(grid, 4 * sc->exact_grid)), dim3(256), 0, st, shc, sc->dev, \
+                       sc->top_args, (const f2*)sc->d_trec, (const float*)sc->d_gst2, (const int*)sc->groups[0].d_slot_pos, \
+                       sc->wb.dirs, sc->wb.tval, sc->wb.q_shade, &sc->wb.cnt->q_shade, sc->wb.hit_id, sc->wb.rgb,           \
+                       sc->wb.cnt, (const int*)sc->wb.tri_hit, (const unsigned*)sc->wb.q_top);                              \
+  } while (0)
+      if (has_top_runs && trace_then_shade()) {
+        if (nearest) RTMI_LAUNCH_TRACE_REPLAY(true);
+        else RTMI_LAUNCH_TRACE_REPLAY(false);
+      } else if (nearest) {
         if (has_top_runs) RTMI_LAUNCH_SHADE((k_shade<true, true>));
         else RTMI_LAUNCH_SHADE((k_shade<false, true>));
       } else {
         if (has_top_runs) RTMI_LAUNCH_SHADE((k_shade<true, false>));
         else RTMI_LAUNCH_SHADE((k_shade<false, false>));
       }
+#undef RTMI_LAUNCH_TRACE_REPLAY
 #undef RTMI_LAUNCH_SHADE
       if (b0 == 0) HIP_TRY(hipEventRecord(sc->ev_d, st));
       shade_queue_launched = true;

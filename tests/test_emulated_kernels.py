@@ -19,7 +19,7 @@ SEARCHES = {"tree": _abi.RTMI_SEARCH_CONE_TREE, "scan": _abi.RTMI_SEARCH_LIST_SC
 PARITY_COUNTERS = ("samples", "rays_reflection", "rays_shadow", "sphere_tests", "primary_hits")
 # kernels whose wave-level votes are meant to be reached by part of a wave (the secondary-ray tree walk is
 # called from divergent shading code); everywhere else a vote that misses live lanes is a defect
-DIVERGENT_OK = ("k_shade<true, ", "k_shade_candidates<true, ")
+DIVERGENT_OK = ("k_shade<true, ", "k_shade_candidates<true, ", "k_trace_top<", "k_shade_replay<")
 
 
 @pytest.fixture(scope="module")
