@@ -143,34 +143,76 @@ k_gen(FrameConst fc, SceneDev sc, const int2* __restrict__ blocks, int nsamples,
 
 // After the top-level triangle search: combine the first sphere-like object (hit_id from
 // k_gen) with the first top-level triangle (tri_hit) by list position.
+// A workgroup serves RESOLVE_ITERS x 256 consecutive queue entries and reserves its part of each output queue
+// with one atomic: every workgroup of the launch adds to the same two counters, and returning atomics on one
+// address are served one after the other.
+constexpr int RESOLVE_ITERS = 8;
 __global__ void __launch_bounds__(256)
 k_resolve_top(SceneDev sc, const int* __restrict__ q_top, const int* __restrict__ nq_ptr, const int* __restrict__ tri_hit,
               const int* __restrict__ tri_owner, int* hit_id, int* q_child, int* q_shade, DevCounters* cnt,
               const double* __restrict__ tval, const double* __restrict__ t_obj, int nearest) {
-  int q = blockIdx.x * blockDim.x + threadIdx.x;
-  bool to_child = false, to_shade = false;
-  int s = -1;
-  if (q < *nq_ptr) {
-    s = checked(q_top[q], sc.n_samples, cnt, 14);
-    int id = hit_id[s];
-    int th = tri_hit[q];
-    if (th >= 0) th = checked(th, sc.n_tris, cnt, 15);
-    int obj = id <= -2 ? -2 - id : 0x7fffffff;
-    if (th >= 0) {
-      const int owner = tri_owner[th];
-      bool take = owner < obj;  // list order (also: no sphere-like hit at all)
-      if (nearest && id <= -2) {  // the smaller parameter wins, list order among equals
-        const double tt = tval[s], to = t_obj[(size_t)s * 3];
-        take = tt < to || (tt == to && owner < obj);
+  __shared__ int wtot[2][RESOLVE_ITERS * 4];  // per output queue: entries of (round, wave), then their exclusive prefix sums
+  __shared__ int gbase[2];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int nq = *nq_ptr;
+  int sv[RESOLVE_ITERS];
+  unsigned child_bits = 0, shade_bits = 0;
+  int rank_child[RESOLVE_ITERS], rank_shade[RESOLVE_ITERS];
+#pragma unroll
+  for (int it = 0; it < RESOLVE_ITERS; ++it) {
+    const int q = (blockIdx.x * RESOLVE_ITERS + it) * 256 + threadIdx.x;
+    bool to_child = false, to_shade = false;
+    int s = -1;
+    if (q < nq) {
+      s = checked(q_top[q], sc.n_samples, cnt, 14);
+      int id = hit_id[s];
+      int th = tri_hit[q];
+      if (th >= 0) th = checked(th, sc.n_tris, cnt, 15);
+      int obj = id <= -2 ? -2 - id : 0x7fffffff;
+      if (th >= 0) {
+        const int owner = tri_owner[th];
+        bool take = owner < obj;  // list order (also: no sphere-like hit at all)
+        if (nearest && id <= -2) {  // the smaller parameter wins, list order among equals
+          const double tt = tval[s], to = t_obj[(size_t)s * 3];
+          take = tt < to || (tt == to && owner < obj);
+        }
+        if (take) { id = th; obj = -1; }
       }
-      if (take) { id = th; obj = -1; }
+      hit_id[s] = id;
+      if (id >= 0) to_shade = true;
+      else if (id <= -2) {
+        if (sc.objects[checked(obj, sc.n_objects, cnt, 16)].kind == RTMI_BOUNDING_SPHERE) to_child = true; else to_shade = true;
+      }
     }
-    hit_id[s] = id;
-    if (id >= 0) to_shade = true;
-    else if (id <= -2) {
-      if (sc.objects[checked(obj, sc.n_objects, cnt, 16)].kind == RTMI_BOUNDING_SPHERE) to_child = true; else to_shade = true;
+    sv[it] = s;
+    const unsigned long long mc = __ballot(to_child), ms = __ballot(to_shade);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    rank_child[it] = __popcll(mc & below);
+    rank_shade[it] = __popcll(ms & below);
+    if (to_child) child_bits |= 1u << it;
+    if (to_shade) shade_bits |= 1u << it;
+    if (lane == 0) {
+      wtot[0][it * 4 + w] = __popcll(mc);
+      wtot[1][it * 4 + w] = __popcll(ms);
     }
   }
-  block_append(&cnt->q_child, q_child, to_child, s);
-  block_append(&cnt->q_shade, q_shade, to_shade, s);
+  __syncthreads();
+  if (threadIdx.x < 128) {  // wave 0 scans the child queue's entries, wave 1 the shade queue's
+    const int k = threadIdx.x >> 6;
+    static_assert(RESOLVE_ITERS * 4 <= 64, "one wave scans the (round, wave) entries of a queue");
+    const int v = lane < RESOLVE_ITERS * 4 ? wtot[k][lane] : 0;
+    int incl = v;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int up = __shfl_up(incl, off);
+      if (lane >= off) incl += up;
+    }
+    if (lane < RESOLVE_ITERS * 4) wtot[k][lane] = incl - v;
+    if (lane == 63) gbase[k] = incl ? atomicAdd(k == 0 ? &cnt->q_child : &cnt->q_shade, incl) : 0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < RESOLVE_ITERS; ++it) {
+    if ((child_bits >> it) & 1u) q_child[gbase[0] + wtot[0][it * 4 + w] + rank_child[it]] = sv[it];
+    if ((shade_bits >> it) & 1u) q_shade[gbase[1] + wtot[1][it * 4 + w] + rank_shade[it]] = sv[it];
+  }
 }

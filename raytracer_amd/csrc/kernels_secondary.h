@@ -61,12 +61,14 @@ struct TopTreeRef {
   const float* gst2;    // per top-level ordinal: plane and edge operands (k_pack_general)
   const int* slot_pos;  // slot -> top-level ordinal (= position among the top-level triangles)
   int ltop, n_root, n_slots, n_records;
+  int cone_levels;      // bit l: the records of level l have cones of normals (a second block after the n_records sphere records)
   int off[TREE_MAX_LEVELS];
 };
 
 // The scalar part of TopTreeRef, passed to the kernels by value.
 struct TopTreeArgs {
   int ltop, n_root, n_slots, n_records;
+  int cone_levels;
   int off[TREE_MAX_LEVELS];
 };
 
@@ -74,6 +76,7 @@ __device__ inline TopTreeRef make_top_tree(const TopTreeArgs& a, const f2* rec, 
   TopTreeRef t;
   t.rec = rec; t.gst2 = gst2; t.slot_pos = slot_pos;
   t.ltop = a.ltop; t.n_root = a.n_root; t.n_slots = a.n_slots; t.n_records = a.n_records;
+  t.cone_levels = a.cone_levels;
 #pragma unroll
   for (int l = 0; l < TREE_MAX_LEVELS; ++l) t.off[l] = a.off[l];
   return t;
@@ -120,11 +123,24 @@ __device__ inline int top_tree_trace(const SceneDev& sc, const TopTreeRef& T, d3
     const f2* rp = T.rec + (size_t)min(level_off(lvl) + ri, T.n_records - 1) * (REC_DWORDS / 2);  // the clamp never binds
     const bool live = !any_only || best == 0x7fffffff;
     unsigned mask = 0;
+    if ((T.cone_levels >> lvl) & 1) {
+      // a node whose triangles all face away from the ray is passed over (tree_sphere_records)
+      const f2* cp = rp + (size_t)T.n_records * (REC_DWORDS / 2);
 #pragma unroll
-    for (int pr = 0; pr < 4; ++pr) {
-      f2 U = pair_u(rp, pr);
-      if (__any(live && !(U.x < 0.0f))) mask |= 1u << (2 * pr);
-      if (__any(live && !(U.y < 0.0f))) mask |= 2u << (2 * pr);
+      for (int pr = 0; pr < 4; ++pr) {
+        const f2 U = pair_u(rp, pr);
+        const f2 ax = cp[pr * 4 + 0], ay = cp[pr * 4 + 1], az = cp[pr * 4 + 2], thr = cp[pr * 4 + 3];
+        const f2 C = __builtin_elementwise_fma(az, Z, __builtin_elementwise_fma(ay, Y, ax * X));
+        if (__any(live && !(U.x < 0.0f) && C.x < thr.x)) mask |= 1u << (2 * pr);
+        if (__any(live && !(U.y < 0.0f) && C.y < thr.y)) mask |= 2u << (2 * pr);
+      }
+    } else {
+#pragma unroll
+      for (int pr = 0; pr < 4; ++pr) {
+        f2 U = pair_u(rp, pr);
+        if (__any(live && !(U.x < 0.0f))) mask |= 1u << (2 * pr);
+        if (__any(live && !(U.y < 0.0f))) mask |= 2u << (2 * pr);
+      }
     }
     return (unsigned)__builtin_amdgcn_readfirstlane((int)mask);
   };
@@ -211,14 +227,12 @@ __device__ inline int top_tree_trace(const SceneDev& sc, const TopTreeRef& T, d3
   return best == 0x7fffffff ? -1 : best;
 }
 
-// traceRay over the whole top-level list (RayTracingFunctions.swift:37-44) for a secondary
-// ray: intersections[0] if want_first, and whether any non-bounding object is hit.
-template <bool HAS_TOP>
-__device__ inline bool trace_top_secondary(const SceneDev& sc, const TopTreeRef& tt, d3 o, d3 d, bool want_first, Hit* h,
-                                           bool* any_non_bounding, tally_t* n_tests) {
+// The sphere-like members of the top-level list (spheres, bounding spheres, lights) for a secondary ray, in list
+// order: intersections[0] among them if want_first (*first_obj = its list index), and whether any of them other
+// than a bounding sphere is hit.  For a shadow ray the first such hit settles the question.
+__device__ inline bool secondary_objects(const SceneDev& sc, d3 o, d3 d, bool want_first, Hit* h, bool* any_non_bounding,
+                                         int* first_obj_out) {
   bool found = false, anb = false;
-  // spheres, bounding spheres and lights first, in list order: for a shadow ray the first
-  // non-bounding hit settles the question and the triangles need not be searched
   int first_obj = 0x7fffffff;  // list index of the first sphere-like hit (want_first)
 #pragma nounroll
   for (int k = 0; k < sc.n_objects; ++k) {
@@ -252,6 +266,21 @@ __device__ inline bool trace_top_secondary(const SceneDev& sc, const TopTreeRef&
       }
     }
   }
+  *any_non_bounding = anb;
+  *first_obj_out = first_obj;
+  return found;
+}
+
+// traceRay over the whole top-level list (RayTracingFunctions.swift:37-44) for a secondary
+// ray: intersections[0] if want_first, and whether any non-bounding object is hit.
+template <bool HAS_TOP>
+__device__ inline bool trace_top_secondary(const SceneDev& sc, const TopTreeRef& tt, d3 o, d3 d, bool want_first, Hit* h,
+                                           bool* any_non_bounding, tally_t* n_tests) {
+  // spheres, bounding spheres and lights first, in list order: for a shadow ray the first
+  // non-bounding hit settles the question and the triangles need not be searched
+  bool anb = false;
+  int first_obj = 0x7fffffff;
+  bool found = secondary_objects(sc, o, d, want_first, h, &anb, &first_obj);
   if constexpr (HAS_TOP) {
     // the top-level triangles: one walk for all runs; a triangle hit wins over the sphere-like
     // hit if its run is listed earlier (RTF:41-43: the first intersection in list order)

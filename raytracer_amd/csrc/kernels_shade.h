@@ -83,16 +83,18 @@ __device__ __forceinline__ bool trace_secondary(const SceneDev& sc, const TopTre
 // The secondary rays of one sample can be traced in one kernel and their outcomes used by another: the tracing
 // kernel wants as many resident waves as it can get (a tree walk is a chain of dependent loads), the lighting
 // arithmetic wants registers.  TRACE_LIVE traces where the lighting needs the outcome (one kernel does both);
-// TRACE_RECORD traces and notes the outcomes in a TraceRec, in the order the lighting asks for them;
-// TRACE_REPLAY takes them from the TraceRec instead of tracing.  Both kernels run the same lighting code on the
-// same operands, so they ask for the same rays in the same order.
+// TRACE_RECORD traces and notes the outcomes in a TraceRec; TRACE_REPLAY takes them from the TraceRec instead of
+// tracing.  A shadow ray's outcome is filed under its light and its depth (shadow_key), so a recorder may trace the
+// rays in any order, and may trace more than the lighting ends up asking for.  At most TRACE_MAX_LIGHTS lights.
 enum { TRACE_LIVE = 0, TRACE_RECORD = 1, TRACE_REPLAY = 2 };
+constexpr int TRACE_MAX_LIGHTS = 16;
 struct TraceRec {
   int id;         // the reflection ray's intersection: triangle index, -2 - object index, or -1 for none
   double t;       // its parameter
-  unsigned bits;  // one bit per shadow ray, in the order they are traced: something other than a bounding sphere was hit
-  int nbits;
+  unsigned bits;  // bit shadow_key(light, depth): that shadow ray hit something other than a bounding sphere
 };
+// depth 0: the shadow rays of the primary hit; depth 1: those of the hit its reflection ray found
+__device__ inline unsigned shadow_key(int light, int depth) { return (unsigned)(light + TRACE_MAX_LIGHTS * depth) & 31u; }
 
 // The reflection ray (RTF:212-216): its first intersection under the frame's hit policy.
 template <int MODE, bool HAS_TOP, bool NEAREST>
@@ -132,19 +134,15 @@ __device__ __forceinline__ bool traced_first(const SceneDev& sc, const TopTreeRe
 
 // A shadow ray (RTF:236-243): does it hit anything other than a bounding sphere.
 template <int MODE, bool HAS_TOP, bool NEAREST>
-__device__ __forceinline__ bool traced_any(const SceneDev& sc, const TopTreeRef& tt, d3 o, d3 d, tally_t* n_tests, TraceRec* rec) {
+__device__ __forceinline__ bool traced_any(const SceneDev& sc, const TopTreeRef& tt, d3 o, d3 d, tally_t* n_tests, TraceRec* rec,
+                                           unsigned key) {
   if constexpr (MODE == TRACE_REPLAY) {
-    const bool anb = (rec->bits >> (rec->nbits & 31)) & 1u;
-    rec->nbits += 1;
-    return anb;
+    return (rec->bits >> key) & 1u;
   } else {
     Hit dummy;
     bool anb = false;
     trace_secondary<HAS_TOP, NEAREST>(sc, tt, o, d, false, &dummy, &anb, n_tests);
-    if constexpr (MODE == TRACE_RECORD) {
-      rec->bits |= (anb ? 1u : 0u) << (rec->nbits & 31);
-      rec->nbits += 1;
-    }
+    if constexpr (MODE == TRACE_RECORD) rec->bits |= (anb ? 1u : 0u) << key;
     return anb;
   }
 }
@@ -248,7 +246,8 @@ __device__ __forceinline__ RGBd calculate_lighting(const SceneDev& sc, const Top
     if (ndl <= 0) continue;
     if constexpr (!INERT) {
       *n_shadow += 1;
-      if (traced_any<MODE, HAS_TOP, NEAREST>(sc, tt, surface_point, point_to_light, n_tests, rec)) continue;  // RTF:241
+      if (traced_any<MODE, HAS_TOP, NEAREST>(sc, tt, surface_point, point_to_light, n_tests, rec, shadow_key(li, REFLECT ? 0 : 1)))
+        continue;  // RTF:241
     }
     if (!has_material) continue; // RTF:245
     double lr = light.diffuse[0], lg = light.diffuse[1], lb = light.diffuse[2];
@@ -282,6 +281,41 @@ __device__ inline void shade_tally_flush(DevCounters* cnt, const ShadeTally& t) 
   wave_count(cnt, C_SHADOW_ELIDED, t.n_elided);
 }
 
+// The intersection of sample s's primary ray (direction d) with `id` (triangle index, or -2 - object index) as the
+// lighting wants it; t_tri is the triangle's intersection parameter.  False if a sphere-like object is missed after all.
+__device__ __forceinline__ bool primary_hit(const SceneDev& sc, d3 cam, d3 d, int id, double t_tri, Hit* h) {
+  bool ok = false;
+  if (id >= 0) {
+    const rtmi_triangle& tr = sc.tris[id];
+    const TriPlane pl = sc.planes[id];
+    // the search already decided this hit with Triangle.intersections; rebuild its point
+    // exactly as Renderables.swift:153 does: origin + intersectionParameter * direction
+    ok = true;
+    h->t = t_tri;
+    h->P = rtx::add(cam, rtx::smul(h->t, d));
+    h->n = rtx::mk(pl.nx, pl.ny, pl.nz);
+    h->has_normal = 1;
+    h->n_unit = 1;
+    h->material = tr.material;
+    h->id = id;
+  } else {
+    const rtmi_object& ob = sc.objects[-2 - id];
+    if (ob.kind == RTMI_LIGHT) {
+      ok = rtx::light_hit(rtx::ld3(sc.lights[ob.first].loc), cam, d, &h->t, &h->P);
+      h->has_normal = 0;
+      h->n_unit = 1;
+      h->material = -1;
+    } else {
+      ok = rtx::sphere_first(rtx::ld3(ob.center), ob.radius, cam, d, &h->t, &h->P, &h->n);
+      h->has_normal = 1;
+      h->n_unit = 1;
+      h->material = ob.material;
+    }
+    h->id = id;
+  }
+  return ok;
+}
+
 // Shade sample s whose primary ray (direction d) hit `id` (triangle index, or -2 - object index);
 // t_tri is the triangle's intersection parameter.  LEAN: returns true, with nothing counted or stored,
 // if the sample needs the full instantiation (see calculate_lighting).
@@ -291,35 +325,7 @@ __device__ __forceinline__ bool shade_sample(const ShadeConst& fc, const SceneDe
                                              int id, double t_tri, double* rgb, ShadeTally* tl, TraceRec* rec = nullptr) {
   d3 cam = rtx::ld3(fc.cam);
   Hit h;
-  bool ok = false;
-  if (id >= 0) {
-    const rtmi_triangle& tr = sc.tris[id];
-    const TriPlane pl = sc.planes[id];
-    // the search already decided this hit with Triangle.intersections; rebuild its point
-    // exactly as Renderables.swift:153 does: origin + intersectionParameter * direction
-    ok = true;
-    h.t = t_tri;
-    h.P = rtx::add(cam, rtx::smul(h.t, d));
-    h.n = rtx::mk(pl.nx, pl.ny, pl.nz);
-    h.has_normal = 1;
-    h.n_unit = 1;
-    h.material = tr.material;
-    h.id = id;
-  } else {
-    const rtmi_object& ob = sc.objects[-2 - id];
-    if (ob.kind == RTMI_LIGHT) {
-      ok = rtx::light_hit(rtx::ld3(sc.lights[ob.first].loc), cam, d, &h.t, &h.P);
-      h.has_normal = 0;
-      h.n_unit = 1;
-      h.material = -1;
-    } else {
-      ok = rtx::sphere_first(rtx::ld3(ob.center), ob.radius, cam, d, &h.t, &h.P, &h.n);
-      h.has_normal = 1;
-      h.n_unit = 1;
-      h.material = ob.material;
-    }
-    h.id = id;
-  }
+  const bool ok = primary_hit(sc, cam, d, id, t_tri, &h);
   RGBd c = {0.0, 0.0, 0.0};
   if (ok) {
     bool defer = false;
@@ -391,7 +397,8 @@ k_shade(ShadeConst fc, SceneDev sc, TopTreeArgs ta, const f2* __restrict__ trec,
 // queue entry, its parameter in the sample's second colour slot) and one bit per shadow ray (rec_bits per queue
 // entry).  Without the colour arithmetic it needs half the registers of k_shade<true>, so twice the waves hide
 // the latency of the walks.  k_shade_replay then evaluates the lighting from the recorded outcomes without
-// tracing anything.  The ray counters are kept by k_trace_top, the hit counter by k_shade_replay.
+// tracing anything.  The sphere tests are counted where the rays are traced, hits and rays by k_shade_replay.
+// k_trace_top runs the lighting code itself in recording mode.
 template <bool NEAREST>
 __global__ void __launch_bounds__(256, TRACE_TOP_WAVES)
 k_trace_top(ShadeConst fc, SceneDev sc, TopTreeArgs ta, const f2* __restrict__ trec, const float* __restrict__ gst2,
@@ -408,14 +415,13 @@ k_trace_top(ShadeConst fc, SceneDev sc, TopTreeArgs ta, const f2* __restrict__ t
     if (id >= 0) id = checked(id, sc.n_tris, cnt, 25);
     else id = -2 - checked(-2 - id, sc.n_objects, cnt, 26);
     TraceRec rec;
-    rec.id = -1; rec.t = 0.0; rec.bits = 0u; rec.nbits = 0;
+    rec.id = -1; rec.t = 0.0; rec.bits = 0u;
     shade_sample<true, false, NEAREST, TRACE_RECORD>(fc, sc, tt, s, d, id, id >= 0 ? tval[s] : 0.0, rgb, &tl, &rec);
     rec_id[q] = rec.id;
     rec_bits[q] = rec.bits;
     rgb[(size_t)s * 3 + 1] = rec.t;
   }
-  tl.n_hit = 0;  // counted by k_shade_replay
-  shade_tally_flush(cnt, tl);
+  wave_count(cnt, C_TESTS_SECONDARY, tl.n_tests);  // hits and rays are counted by k_shade_replay
 }
 
 template <bool NEAREST>
@@ -440,12 +446,9 @@ k_shade_replay(ShadeConst fc, SceneDev sc, TopTreeArgs ta, const f2* __restrict_
     else if (rec.id <= -2) rec.id = -2 - checked(-2 - rec.id, sc.n_objects, cnt, 31);
     rec.t = rgb[(size_t)s * 3 + 1];
     rec.bits = rec_bits[q];
-    rec.nbits = 0;
-    ShadeTally rays;  // the rays were counted when they were traced
-    shade_sample<true, false, NEAREST, TRACE_REPLAY>(fc, sc, tt, s, d, id, id >= 0 ? tval[s] : 0.0, rgb, &rays, &rec);
-    tl.n_hit += rays.n_hit;
+    shade_sample<true, false, NEAREST, TRACE_REPLAY>(fc, sc, tt, s, d, id, id >= 0 ? tval[s] : 0.0, rgb, &tl, &rec);
   }
-  shade_tally_flush(cnt, tl);
+  shade_tally_flush(cnt, tl);  // n_tests stays zero here: the tests were counted where the rays were traced
 }
 
 // The cone tree's last stage for the children of a bounding object: one lane per candidate

@@ -97,6 +97,14 @@ static int32_t guarded(F&& body) {
 // Device memory a frame needs beyond the scene itself.  Per sample of a batch: outcome, queues, ray
 // direction, intersection parameter, colour, lowest list position; the candidate lists of the tree
 // search; the per-column and per-row sample tables; the list of 8x8 pixel blocks.
+// RTMI_NORMAL_CONES=0: secondary rays do not use the cones of normals of the bounding-sphere tree (for comparison).
+static bool normal_cones_enabled() {
+  static bool v = [] {
+    const char* e = getenv("RTMI_NORMAL_CONES");
+    return !(e && atoi(e) == 0);
+  }();
+  return v;
+}
 struct WorkBufs {
   size_t cap_samples = 0;
   int* hit_id = nullptr;
@@ -580,7 +588,9 @@ static int32_t scene_create_impl(const rtmi_scene_desc* desc, int32_t device, rt
     HIP_TRY(hipGetLastError());
     // bounding-sphere tree over the slot order of group 0
     std::vector<float> trec;
-    tree_sphere_records(desc->triangles, sc->groups[0].tree_host, c0, r_o1, &trec);
+    unsigned cone_levels = 0;
+    tree_sphere_records(desc->triangles, sc->groups[0].tree_host, c0, r_o1, &trec, &cone_levels);
+    sc->top_args.cone_levels = normal_cones_enabled() ? (int)cone_levels : 0;
     if ((rc = upload((void**)&sc->d_trec, trec.data(), sizeof(float) * trec.size()))) return rc;
     const TreeDev& td = sc->groups[0].tree;
     sc->top_args.ltop = td.ltop;
@@ -1104,7 +1114,7 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
     };
     if (sc->groups[0].n > 0) {
       if ((rc = search_group(0))) return rc;
-      hipLaunchKernelGGL(k_resolve_top, dim3(grid), dim3(256), 0, st, sc->dev, sc->wb.q_top, &sc->wb.cnt->q_top, sc->wb.tri_hit,
+      hipLaunchKernelGGL(k_resolve_top, dim3((grid + RESOLVE_ITERS - 1) / RESOLVE_ITERS), dim3(256), 0, st, sc->dev, sc->wb.q_top, &sc->wb.cnt->q_top, sc->wb.tri_hit,
                          sc->d_tri_owner, sc->wb.hit_id, sc->wb.q_child, sc->wb.q_shade, sc->wb.cnt, (const double*)sc->wb.tval,
                          (const double*)sc->wb.rgb, nearest ? 1 : 0);
     }
@@ -1131,7 +1141,7 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
                        sc->wb.dirs, sc->wb.tval, sc->wb.q_shade, &sc->wb.cnt->q_shade, sc->wb.hit_id, sc->wb.rgb,           \
                        sc->wb.cnt, (const int*)sc->wb.tri_hit, (const unsigned*)sc->wb.q_top);                              \
   } while (0)
-      if (has_top_runs && trace_then_shade()) {
+      if (has_top_runs && trace_then_shade() && sc->dev.n_lights <= TRACE_MAX_LIGHTS) {
         if (nearest) RTMI_LAUNCH_TRACE_REPLAY(true);
         else RTMI_LAUNCH_TRACE_REPLAY(false);
       } else if (nearest) {

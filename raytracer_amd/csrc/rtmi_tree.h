@@ -153,11 +153,60 @@ static void tree_build_host(const rtmi_triangle* tris, const std::vector<int>& i
 // FP32 evaluation error of T (about 40*2^-24*(|c|_1+|o|_1)^2).  Coordinates are relative to c0; r_o1
 // bounds |o - c0|_1 over every possible ray origin.  Absent children get nK = -3e38 (never pass),
 // non-finite ones +3e38 (always pass).
+//
+// A second block of th.n_records records follows the first, in the same layout: per sphere a cone of normals
+// (ax, ay, az, thr) over the triangles below that node.  A triangle is only hit from its front, normal.direction < 0
+// (REN:145-146); if every normal below a node lies within theta < 90 deg of the unit axis a, then
+// a.direction >= sin(theta) makes every normal.direction >= 0 and the node can be passed over.  thr = sin(theta) +
+// 1e-4 (the margin covers the FP32 evaluation and directions that are unit vectors only to rounding); +3e38 where
+// no such cone exists (never passed over).  Filled for levels >= 1; *cone_levels gets a bit per level that has
+// at least one usable cone.
 static void tree_sphere_records(const rtmi_triangle* tris, const TreeHost& th, const double c0[3], double r_o1,
-                                std::vector<float>* out) {
+                                std::vector<float>* out, unsigned* cone_levels) {
   struct Sph { double c[3]; double r; bool valid; };
   const TreeDev& d = th.dev;
-  out->assign(th.n_records * REC_DWORDS, 0.0f);
+  out->assign(2 * th.n_records * REC_DWORDS, 0.0f);
+  {
+    float* cone = out->data() + th.n_records * REC_DWORDS;
+    for (size_t r = 0; r < th.n_records; ++r)
+      for (int pr = 0; pr < 4; ++pr) cone[r * REC_DWORDS + pr * 8 + 6] = cone[r * REC_DWORDS + pr * 8 + 7] = 3.0e38f;
+    *cone_levels = 0;
+    // unit normals per slot (Renderables.swift:136: normalize(cross(v1 - v0, v2 - v0))); absent or degenerate: skipped
+    const int ns = d.n_nodes[0];
+    std::vector<double> nrm((size_t)ns * 3, 0.0);
+    std::vector<char> has((size_t)ns, 0);
+    for (int p = 0; p < ns; ++p) {
+      const int ti = th.slot_tri[p];
+      if (ti < 0) continue;
+      double e1[3], e2[3];
+      for (int a = 0; a < 3; ++a) { e1[a] = tris[ti].v[1][a] - tris[ti].v[0][a]; e2[a] = tris[ti].v[2][a] - tris[ti].v[0][a]; }
+      const double cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
+      const double len = sqrt(cx * cx + cy * cy + cz * cz);
+      // a triangle without a finite unit normal is never hit (its normal.direction is NaN): it constrains nothing
+      if (!(len > 0) || !std::isfinite(len)) continue;
+      nrm[(size_t)p * 3 + 0] = cx / len; nrm[(size_t)p * 3 + 1] = cy / len; nrm[(size_t)p * 3 + 2] = cz / len;
+      has[p] = 1;
+    }
+    long long span = 1;
+    for (int L = 1; L <= d.ltop; ++L) {
+      span *= 8;
+      for (int j = 0; j < d.n_nodes[L]; ++j) {
+        const long long p0 = (long long)j * span, p1 = std::min<long long>(p0 + span, ns);
+        double ax = 0, ay = 0, az = 0;
+        for (long long p = p0; p < p1; ++p) if (has[p]) { ax += nrm[p * 3]; ay += nrm[p * 3 + 1]; az += nrm[p * 3 + 2]; }
+        const double al = sqrt(ax * ax + ay * ay + az * az);
+        if (!(al > 1e-9)) continue;
+        ax /= al; ay /= al; az /= al;
+        double cmin = 1.0;
+        for (long long p = p0; p < p1; ++p) if (has[p]) cmin = std::min(cmin, ax * nrm[p * 3] + ay * nrm[p * 3 + 1] + az * nrm[p * 3 + 2]);
+        if (!(cmin > 0.1)) continue;  // wider than about 84 degrees: not worth a test
+        const double sin_theta = sqrt(std::max(0.0, 1.0 - std::min(cmin, 1.0) * std::min(cmin, 1.0)));
+        float* dst = cone + (size_t)(d.rec_off[L] + (j >> 3)) * REC_DWORDS + ((j & 7) >> 1) * 8 + (j & 1);
+        dst[0] = (float)ax; dst[2] = (float)ay; dst[4] = (float)az; dst[6] = (float)(sin_theta + 1e-4);
+        *cone_levels |= 1u << L;
+      }
+    }
+  }
   // nodes that do not exist (the tail of a level's last record) must never pass: an all-zero entry
   // WOULD pass for a ray whose line runs through c0
   for (size_t r = 0; r < th.n_records; ++r)
