@@ -192,8 +192,19 @@ RT_HD bool sphere_any_ahead(d3 location, double radius, d3 origin, d3 direction)
 }
 
 // PointLight.intersections (REN:80-91) with eq3 (UTL:155-157).
+// The three quotients can only be equal if num and direction are parallel to within rounding: tx == ty makes
+// num.x * direction.y and num.y * direction.x agree to 2^-52 relative, and a pair of products further apart than
+// 1e-12 relative (the slack covers the rounding of the products and of their difference many times over) rules the
+// hit out without a division.  A NaN or an overflow in the products fails the comparison and the divisions decide.
 RT_HD bool light_hit(d3 location, d3 origin, d3 direction, double* t_out, d3* P_out) {
   d3 num = sub(location, origin);
+  {
+    const double pxy = num.x * direction.y, pyx = num.y * direction.x;
+    const double pyz = num.y * direction.z, pzy = num.z * direction.y;
+    const double sxy = fabs(pxy) + fabs(pyx), syz = fabs(pyz) + fabs(pzy);
+    // (products near the subnormal range carry no such relative accuracy: those go to the divisions too)
+    if ((sxy > 1e-290 && fabs(pxy - pyx) > 1e-12 * sxy) || (syz > 1e-290 && fabs(pyz - pzy) > 1e-12 * syz)) return false;
+  }
   double tx = num.x / direction.x, ty = num.y / direction.y, tz = num.z / direction.z;
   if (tx >= 0.0000001 && (!isinf(tx) && tx == ty && ty == tz)) {
     *t_out = tx;
