@@ -28,3 +28,25 @@ def light_hit_scene(oracle_mod):
     data = scenes.SceneData(lights=lights, materials=scenes.material(**scenes.VC_MATERIAL), objects=objects,
                             triangles=np.zeros(0, scenes.TRI_DTYPE))
     return data, cam, scenes.make_params(W, H, 1.0), pixels
+
+
+def toplevel_mesh_with_company(n_lights, level=2):
+    """A non-convex mesh listed at top level, a sphere with a material beside it and a light in the object list:
+    reflection rays find the mesh, the sphere and the light; shadow rays are blocked by mesh and sphere.
+    n_lights point lights on a ring (more than 16 takes the shading kernel that traces its own rays)."""
+    import math
+    from raytracer_amd import scenes
+    v, f = scenes.displaced_icosphere(level)
+    tris = scenes.triangles_from_vertices(v, f, 0)
+    tris["material"][::3] = 1
+    lights = np.concatenate([
+        scenes.light(loc=(6.0 * math.cos(2.4 * k), 3.0 + 0.37 * k, 6.0 * math.sin(2.4 * k)), specular=(0.5, 0.5, 0.5),
+                     diffuse=(1.7 / n_lights, 1.5 / n_lights, 1.6 / n_lights)) for k in range(n_lights)])
+    mats = np.concatenate([scenes.material(**scenes.VC_MATERIAL),
+                           scenes.material(Ns=5.0, d=1.0, illum=2, Kd=(0.8, 0.3, 0.2), Ka=(0.2, 0.5, 0.9), Ks=(0.4, 0.9, 0.1))])
+    objects = np.concatenate([
+        scenes.sphere_object((1.6, 0.3, 0.4), 0.5, 1),
+        scenes.triangles_object(0, len(tris)),
+        scenes.light_object(0),
+    ])
+    return scenes.SceneData(lights=lights, materials=mats, objects=objects, triangles=tris)

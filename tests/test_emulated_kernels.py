@@ -12,7 +12,7 @@ import pytest
 
 import emu_util
 from golden_util import golden_names, load_golden
-from scene_cases import light_hit_scene
+from scene_cases import light_hit_scene, toplevel_mesh_with_company
 from raytracer_amd import _abi, scenes, sharding
 
 SEARCHES = {"tree": _abi.RTMI_SEARCH_CONE_TREE, "scan": _abi.RTMI_SEARCH_LIST_SCAN}
@@ -333,3 +333,28 @@ def test_emulated_pixels_only_flag_gives_the_same_frame(emu, oracle_mod, tmp_pat
     assert (hit[:31, :39] == o_hit[:31, :39]).all() and (rgba[:31, :39] == o_rgba[:31, :39]).all()
     assert cnt.rays_reflection == o_cnt["rays_reflection"] and cnt.rays_shadow == o_cnt["rays_shadow"]
     assert not any("k_shade_candidates<false, true>" in k for k in stats)
+
+
+@pytest.mark.parametrize("env", [None, {"RTMI_TRACE_THEN_SHADE": "0"}, {"RTMI_NORMAL_CONES": "0"}])
+def test_emulated_secondary_rays_of_toplevel_triangles(emu, oracle_mod, tmp_path, env):
+    """Secondary rays that do find things -- a non-convex top-level mesh next to a sphere, a light in the object
+    list -- traced in one kernel and shaded in another (the default), traced by the shading kernel itself, and
+    without the cones of normals in the bounding-sphere tree: always the oracle's frame and ray counts."""
+    data = toplevel_mesh_with_company(3)
+    cams = [scenes.make_camera((0.9, 0.5, 4.0), (-0.12, -0.1, -1.0), 8.0)]
+    run_case(emu, oracle_mod, tmp_path, data, cams, scenes.make_params(46, 34, 0.5), searches=("tree",), env=env)
+
+
+def test_emulated_more_lights_than_the_trace_record_holds(emu, oracle_mod, tmp_path):
+    """Seventeen lights: one more than the recorded shadow-ray outcomes of a sample have room for, so the frame
+    goes through the shading kernel that traces its own rays; sixteen lights still take the two-kernel path."""
+    cams = [scenes.make_camera((0.9, 0.5, 4.0), (-0.12, -0.1, -1.0), 8.0)]
+    params = scenes.make_params(30, 24, 1.0)
+    for n in (17, 16):
+        data = toplevel_mesh_with_company(n, level=1)
+        expected = [oracle_mod.render(data, c, params, threads=8) for c in cams]
+        frames, stats, _ = emu.run_emulated(data, cams, params, tmp_path / str(n))
+        check_frames(frames, stats, expected, params)
+        recorded = any("k_shade_replay<" in name for name in stats)
+        assert recorded == (n == 16), sorted(stats)
+        assert any("k_shade<true, " in name for name in stats) == (n == 17), sorted(stats)

@@ -603,3 +603,15 @@ def test_nearest_hit_extension(oracle_mod, rt):
             sc.render(c_, scenes.make_params(W, H, sub, hit_policy=_abi.RTMI_HIT_NEAREST, search=_abi.RTMI_SEARCH_LIST_SCAN))
         sc.close()
     assert differs > 1000
+
+
+@pytest.mark.parametrize("n_lights", [3, 16, 17])
+def test_secondary_rays_of_toplevel_triangles_find_mesh_sphere_and_light(oracle_mod, rt, n_lights):
+    """A non-convex top-level mesh beside a sphere with a material, a light in the object list: reflection rays
+    find all three, shadow rays are blocked by mesh and sphere.  Up to 16 lights the rays of a hit are traced by
+    one kernel and their recorded outcomes shaded by another; 17 lights go through the kernel that does both."""
+    from scene_cases import toplevel_mesh_with_company
+    data = toplevel_mesh_with_company(n_lights, level=3)
+    cam = scenes.make_camera((0.9, 0.5, 4.0), (-0.12, -0.1, -1.0), 8.0)
+    o, g = assert_parity(oracle_mod, rt, data, cam, scenes.make_params(200, 150, 0.5 if n_lights == 3 else 1.0))
+    assert o["rays_reflection"] == o["primary_hits"] > 0 and o["rays_shadow"] > o["rays_reflection"]
