@@ -365,7 +365,9 @@ def shade_roofline(args, totals, steps, n_lights, inert):
     ms_shade = totals["ms_shade"] / steps
     hits = totals["primary_hits"] / steps
     achieved = hits * flops_hit / (ms_shade * 1e-3) / 1e12 if ms_shade > 0 else 0.0
-    kernel = "k_shade_candidates<false, true>" if inert else ("k_shade_candidates<false, false>" if args.form == "B" else "k_shade<true>")
+    # template arguments: <top-level runs, pixels only on an inert scene, nearest-hit policy>
+    kernel = ("k_shade_candidates<false, true, false>" if inert else
+              ("k_shade_candidates<false, false, false>" if args.form == "B" else "k_trace_top<false>"))
     bytes_hit = 64  # candidate entry 8 + best position 4 + direction 24 read; hit id 4 + colour 24 written
     pmc = pmc_fractions(pmc_kernel(args.config, kernel))
     return {
