@@ -718,14 +718,19 @@ static int32_t pack_group(rtmi_scene* sc, TriGroup& g, d3 cam) {
   return RTMI_OK;
 }
 
-static int search_rays_per_lane() {
-  // rays per lane of k_search_primary; RTMI_SEARCH_R=4|8 overrides the default for experiments
-  static int r = [] {
+// Rays per lane of the search kernels; RTMI_SEARCH_R=2|4|8 overrides the choice for experiments.  The list scan
+// takes 4.  The tree search takes 4 on large batches and 2 on small ones: a wave's walk is one serial chain of
+// record fetches whatever the number of rays it carries, and a small batch (a 1080p frame at 4 samples per pixel is
+// 8 M samples) has too few waves at 4 rays per lane to hide that chain -- measured on the 1.3 M-triangle mesh at
+// 1080p: 1.40 ms per frame with 2 rays per lane, 1.67 with 4; at 4K and 16 samples per pixel 4 wins by 11 %.
+static int search_rays_per_lane(bool tree, int nsamples) {
+  static int forced = [] {
     const char* e = getenv("RTMI_SEARCH_R");
-    int v = e ? atoi(e) : 4;
-    return (v == 8 || v == 2) ? v : 4;
+    int v = e ? atoi(e) : 0;
+    return (v == 8 || v == 2 || v == 4) ? v : 0;
   }();
-  return r;
+  if (forced) return forced;
+  return tree && nsamples <= (16 << 20) ? 2 : 4;
 }
 // Scenes with top-level triangle runs: trace the queued hits' secondary rays in one kernel and shade from the
 // recorded outcomes in another (the default), or do both in one kernel (RTMI_TRACE_THEN_SHADE=0, for comparison).
@@ -1062,7 +1067,7 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
     int grid = (nsamples + 255) / 256;
     hipLaunchKernelGGL(k_gen, dim3((nsamples + 256 * GEN_ITERS - 1) / (256 * GEN_ITERS)), dim3(256), 0, st, fcb, sc->dev, d_blk, nsamples, sc->wb.hit_id, sc->wb.dirs, sc->wb.q_child,
                        sc->wb.q_shade, sc->wb.q_top, sc->wb.cnt, sc->wb.rgb);
-    const int SR = search_rays_per_lane();
+    const int SR = search_rays_per_lane(use_tree, nsamples);
     const int search_grid = (nsamples + 256 * SR - 1) / (256 * SR);
     auto scan_kernel = SR == 8 ? k_search_primary<8> : (SR == 2 ? k_search_primary<2> : k_search_primary<4>);
     auto tree_kernel = SR == 8 ? k_search_tree<8> : (SR == 2 ? k_search_tree<2> : k_search_tree<4>);
