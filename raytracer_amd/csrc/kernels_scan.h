@@ -147,17 +147,21 @@ k_search_primary(const SearchArgs* __restrict__ ap, const f2* __restrict__ cone)
 
   int done_batches = nbatch;
   if (nbatch > 0) {
-    f2 cur[12];
-    int flag = reinterpret_cast<const int*>(cone)[CONE_FLAG];
+    // The batch's flag word travels with its operands (13th pair of the batch) rather than as a scalar of its
+    // own: hipcc 7.2 lost the update of a separate `flag = next flag` on the path that leaves the rare branch, so
+    // the batch after a closely examined one ran with a stale flag (found by tests/gpu_fuzz.py; the ISA showed it).
+    constexpr int NCUR = CONE_FLAG / 2 + 1;
+    static_assert(CONE_FLAG % 2 == 0 && NCUR * 2 <= CONE_DWORDS, "the flag is the first half of the pair after the operands");
+    f2 cur[NCUR];
 #pragma unroll
-    for (int c = 0; c < 12; ++c) cur[c] = cone[c];
+    for (int c = 0; c < NCUR; ++c) cur[c] = cone[c];
     for (int b = 0; b < nbatch; ++b) {
       // request the next batch (one spare, zero-filled batch is allocated past the end)
-      f2 nxt[12];
+      f2 nxt[NCUR];
       const f2* np_ = cone + (size_t)(b + 1) * (CONE_DWORDS / 2);
 #pragma unroll
-      for (int c = 0; c < 12; ++c) nxt[c] = np_[c];
-      int nflag = reinterpret_cast<const int*>(np_)[CONE_FLAG];
+      for (int c = 0; c < NCUR; ++c) nxt[c] = np_[c];
+      const bool flagged = __builtin_bit_cast(int, cur[NCUR - 1].x) != 0;
 
       // R independent chains per triangle pair so that consecutive instructions do not depend
       // on each other
@@ -180,7 +184,7 @@ k_search_primary(const SearchArgs* __restrict__ ap, const f2* __restrict__ cone)
 #pragma unroll
       for (int r = 1; r < R; ++r) mx = __builtin_fmaxf(mx, mxr[r]);
 
-      if (__builtin_expect(__any(mx >= 1.0f) || flag != 0, 0)) {
+      if (__builtin_expect(__any(mx >= 1.0f) || flagged, 0)) {
         // ---- rare path: look closer at the eight triangles of this batch, in list order ----
         const SearchArgs* a2 = ap;
         asm volatile("" : RTMI_SCALAR_REG(a2));  // read the argument block here, not ahead of the loop
@@ -248,8 +252,7 @@ k_search_primary(const SearchArgs* __restrict__ ap, const f2* __restrict__ cone)
         if (__all(all_done)) { done_batches = b + 1; break; }
       }
 #pragma unroll
-      for (int c = 0; c < 12; ++c) cur[c] = nxt[c];
-      flag = nflag;
+      for (int c = 0; c < NCUR; ++c) cur[c] = nxt[c];
     }
   }
 
