@@ -626,3 +626,11 @@ def test_random_scenes_of_the_fuzzer(oracle_mod):
     flag (a scalar the compiler failed to update on that path; the CPU-emulated kernels cannot show such a thing)."""
     import gpu_fuzz
     assert gpu_fuzz.main(["--cases", "320", "--seed", "31"]) == 0
+
+
+def test_random_closed_meshes_at_top_level(oracle_mod):
+    """The fuzzer's mesh cases: displaced icospheres listed at top level (some inside out, some open, some
+    overlapping) among spheres, lights and bounded soups; per case two cameras, the pixels-only flag, and every fourth
+    case 5 to 20 extra lights.  These are the scenes whose bounding-sphere tree has cones of normals."""
+    import gpu_fuzz
+    assert gpu_fuzz.main(["--cases", "200", "--seed", "61", "--meshes", "--extras"]) == 0
