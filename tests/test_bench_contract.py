@@ -24,7 +24,7 @@ def test_kernels_named_by_bench_have_committed_counters():
 
 
 def test_bench_line_on_file_is_a_fraction_free_of_values_above_one():
-    """The committed bench line of this round: every fraction in it is at most 1, the headline is traced rays."""
+    """The committed bench line: every fraction in it is at most 1, the headline is traced rays."""
     line = open(os.path.join(ROOT, "profiles", "r02_bench_c3.json")).read().strip().splitlines()[-1]
     d = json.loads(line)
     assert d["unit"] == "Mrays/s" and d["roofline"]["frac"] <= 1 and d["vs_baseline"] is None
