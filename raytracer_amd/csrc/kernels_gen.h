@@ -8,7 +8,10 @@
 // With no top-level triangle runs the sample is resolved here: a sphere or light hit goes to
 // the shade queue, a bounding-sphere hit to the child-search queue.  With top-level runs
 // every rendered sample goes on to the top-level triangle search, which resolves it.
-constexpr int GEN_ITERS = 8;  // samples per thread in k_gen; a workgroup covers 2048 consecutive samples
+#ifndef RTMI_GEN_ITERS
+#define RTMI_GEN_ITERS 8
+#endif
+constexpr int GEN_ITERS = RTMI_GEN_ITERS;  // samples per thread in k_gen; a workgroup covers 2048 consecutive samples
 
 // One thread per 8x8 pixel block: can any sample of the block come near any sphere-like object?  The sample
 // positions of a block lie within 4 pixels of its centre in both directions, so their focal-plane points lie
@@ -146,7 +149,10 @@ k_gen(FrameConst fc, SceneDev sc, const int2* __restrict__ blocks, int nsamples,
 // A workgroup serves RESOLVE_ITERS x 256 consecutive queue entries and reserves its part of each output queue
 // with one atomic: every workgroup of the launch adds to the same two counters, and returning atomics on one
 // address are served one after the other.
-constexpr int RESOLVE_ITERS = 8;
+#ifndef RTMI_RESOLVE_ITERS
+#define RTMI_RESOLVE_ITERS 16
+#endif
+constexpr int RESOLVE_ITERS = RTMI_RESOLVE_ITERS;
 __global__ void __launch_bounds__(256)
 k_resolve_top(SceneDev sc, const int* __restrict__ q_top, const int* __restrict__ nq_ptr, const int* __restrict__ tri_hit,
               const int* __restrict__ tri_owner, int* hit_id, int* q_child, int* q_shade, DevCounters* cnt,
