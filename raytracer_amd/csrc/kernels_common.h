@@ -26,6 +26,16 @@ template <class T>
 __device__ inline T* as_global(T* p) { return p; }
 #endif
 
+// The lane mask of a predicate.  Votes on a conjunction are written as the AND of the masks of its compares: the
+// compiler turns the ballot of a compare into the compare itself (its result is a lane mask in scalar registers),
+// whereas the ballot -- or HIP's __any() -- of a combined boolean first makes a per-lane 0/1 of it and compares that
+// again, two vector instructions per vote; the walks vote sixteen times per tree record.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ unsigned long long wave_mask(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+#else
+__device__ inline unsigned long long wave_mask(bool p) { return __ballot(p); }
+#endif
+
 struct FrameConst {
   double ul[3], u[3], v[3], cam[3];
   double ppw_h, ppw_v, sub;

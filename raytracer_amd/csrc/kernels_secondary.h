@@ -121,7 +121,7 @@ __device__ inline int top_tree_trace(const SceneDev& sc, const TopTreeRef& T, d3
   };
   auto eval = [&](int lvl, int ri) -> unsigned {
     const f2* rp = T.rec + (size_t)min(level_off(lvl) + ri, T.n_records - 1) * (REC_DWORDS / 2);  // the clamp never binds
-    const bool live = !any_only || best == 0x7fffffff;
+    const unsigned long long live = wave_mask(!any_only || best == 0x7fffffff);
     unsigned mask = 0;
     if ((T.cone_levels >> lvl) & 1) {
       // a node whose triangles all face away from the ray is passed over (tree_sphere_records)
@@ -131,23 +131,24 @@ __device__ inline int top_tree_trace(const SceneDev& sc, const TopTreeRef& T, d3
         const f2 U = pair_u(rp, pr);
         const f2 ax = cp[pr * 4 + 0], ay = cp[pr * 4 + 1], az = cp[pr * 4 + 2], thr = cp[pr * 4 + 3];
         const f2 C = __builtin_elementwise_fma(az, Z, __builtin_elementwise_fma(ay, Y, ax * X));
-        if (__any(live && !(U.x < 0.0f) && C.x < thr.x)) mask |= 1u << (2 * pr);
-        if (__any(live && !(U.y < 0.0f) && C.y < thr.y)) mask |= 2u << (2 * pr);
+        if (live & wave_mask(!(U.x < 0.0f)) & wave_mask(C.x < thr.x)) mask |= 1u << (2 * pr);
+        if (live & wave_mask(!(U.y < 0.0f)) & wave_mask(C.y < thr.y)) mask |= 2u << (2 * pr);
       }
     } else {
 #pragma unroll
       for (int pr = 0; pr < 4; ++pr) {
         f2 U = pair_u(rp, pr);
-        if (__any(live && !(U.x < 0.0f))) mask |= 1u << (2 * pr);
-        if (__any(live && !(U.y < 0.0f))) mask |= 2u << (2 * pr);
+        if (live & wave_mask(!(U.x < 0.0f))) mask |= 1u << (2 * pr);
+        if (live & wave_mask(!(U.y < 0.0f))) mask |= 2u << (2 * pr);
       }
     }
-    return (unsigned)__builtin_amdgcn_readfirstlane((int)mask);
+    return mask;
   };
   auto leaf = [&](int ri) {
     if ((unsigned)(ri * 8) >= (unsigned)T.n_slots) return;  // cannot happen (absent nodes never pass); keeps a bad record from becoming a bad address
     const f2* rp = T.rec + (size_t)(T.off[0] + ri) * (REC_DWORDS / 2);
     const bool live = !any_only || best == 0x7fffffff;
+    const unsigned long long live_m = wave_mask(live);
     if (live) ++leaf_visits;
 #pragma unroll
     for (int pr = 0; pr < 4; ++pr) {
@@ -155,28 +156,34 @@ __device__ inline int top_tree_trace(const SceneDev& sc, const TopTreeRef& T, d3
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const float u = h ? U.y : U.x;
+        // `cand` is the lane's own answer, `cm` the same for the whole wave (see wave_mask)
         bool cand = live && !(u < 0.0f);
-        if (!__any(cand)) continue;
+        unsigned long long cm = live_m & wave_mask(!(u < 0.0f));
+        if (!cm) continue;
         const int g = T.slot_pos[ri * 8 + pr * 2 + h];  // top-level ordinal
         if ((unsigned)g >= (unsigned)sc.n_top_tris) continue;  // padding slot (its sphere passes nothing; belt and braces)
-        cand = cand && (any_only ? best == 0x7fffffff : g < best);  // a later list position cannot replace the hit
-        if (!__any(cand)) continue;
+        // a later list position cannot replace the hit
+        cand = cand && (any_only ? best == 0x7fffffff : g < best);
+        cm &= any_only ? wave_mask(best == 0x7fffffff) : wave_mask(g < best);
+        if (!cm) continue;
         const float* s2 = T.gst2 + (size_t)g * GST2_FLOATS;
         {
           const float nx = s2[0], ny = s2[1], nz = s2[2], cpl = s2[3], Ea = s2[4], Eb = s2[5];
           float nd = __builtin_fmaf(nz, dz, __builtin_fmaf(ny, dy, nx * dx));
           float no = __builtin_fmaf(nz, oz, __builtin_fmaf(ny, oy, nx * ox)) - cpl;
           cand = cand && (nd <= Ea) && (no >= -Eb);
+          cm &= wave_mask(nd <= Ea) & wave_mask(no >= -Eb);
         }
-        if (!__any(cand)) continue;
+        if (!cm) continue;
 #pragma unroll
         for (int e = 0; e < 3; ++e) {
           const float* w = s2 + 9 + e * 6;
           float sv = __builtin_fmaf(w[2], dz, __builtin_fmaf(w[1], dy, w[0] * dx));
           sv = __builtin_fmaf(w[5], mz_, __builtin_fmaf(w[4], my_, __builtin_fmaf(w[3], mx_, sv)));
           cand = cand && (sv <= s2[6 + e]);
+          cm &= wave_mask(sv <= s2[6 + e]);
         }
-        if (!__any(cand)) continue;
+        if (!cm) continue;
         if (cand) {
           const int ti = min(max(sc.top_group[g], 0), sc.n_tris - 1);  // the clamps never bind
           const rtmi_triangle& tr = sc.tris[ti];
