@@ -4,7 +4,8 @@
 // Vectors are drawn from several families that stress the rounding of a quotient: random mantissas with
 // exponents spread over a wide or a narrow range, mantissas of all ones or all zeros (powers of two), components
 // that are tiny fractions of the length, axis-aligned and near-axis vectors, and vectors far outside the guard's
-// range (which must take the plain divisions and still agree).
+// range (which must take the plain divisions and still agree).  rtx::normalize3 (three at once) is held to
+// rtx::normalize on every run of three consecutive vectors, which mixes guarded and unguarded ones.
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -41,11 +42,12 @@ static double draw(uint64_t& s, int family) {
 int main(int argc, char** argv) {
   const long long millions = argc > 1 ? atoll(argv[1]) : 20;
   uint64_t seed = argc > 2 ? strtoull(argv[2], nullptr, 10) : 12345;
-  long long bad = 0, fast = 0;
+  long long bad = 0, fast = 0, bad3 = 0;
   const long long n = millions * 1000000LL;
-#pragma omp parallel for reduction(+ : bad, fast) schedule(static)
+#pragma omp parallel for reduction(+ : bad, fast, bad3) schedule(static)
   for (long long chunk = 0; chunk < n / 1000; ++chunk) {
     uint64_t s = (seed + 0x9E3779B97F4A7C15ull * (uint64_t)(chunk + 1)) | 1;
+    rtx::d3 recent[3];  // the last three vectors: normalize3 must agree with normalize on every triple
     for (int k = 0; k < 1000; ++k) {
       const int family = (int)(next(s) % 8);
       rtx::d3 v = rtx::mk(draw(s, family), draw(s, family), draw(s, (next(s) & 3) ? family : 0));
@@ -61,10 +63,22 @@ int main(int argc, char** argv) {
         if (bad < 5) fprintf(stderr, "mismatch: (%a, %a, %a) -> (%a, %a, %a), expected (%a, %a, %a)\n", v.x, v.y, v.z, g.x, g.y, g.z, ex, ey, ez);
         ++bad;
       }
+      recent[k % 3] = v;
+      if (k >= 2) {
+        rtx::d3 out[3];
+        rtx::normalize3(recent, out);
+        for (int q = 0; q < 3; ++q) {
+          const rtx::d3 one = rtx::normalize(recent[q]);
+          if (memcmp(&one, &out[q], sizeof(one)) != 0 &&
+              !(std::isnan(one.x) && std::isnan(out[q].x)) && !(std::isnan(one.y) && std::isnan(out[q].y)) && !(std::isnan(one.z) && std::isnan(out[q].z)))
+            ++bad3;
+        }
+      }
       const double lo = 3.054936363499605e-151, hi = 3.273390607896142e+150;
       if (length >= lo && length <= hi && fabs(v.x) >= lo && fabs(v.y) >= lo && fabs(v.z) >= lo) ++fast;
     }
   }
-  printf("normalize_check: %lld vectors, %lld through the shared division, %lld mismatches\n", n, fast, bad);
-  return bad ? 1 : 0;
+  printf("normalize_check: %lld vectors, %lld through the shared division, %lld mismatches; normalize3 against normalize: %lld mismatches\n",
+         n, fast, bad, bad3);
+  return bad || bad3 ? 1 : 0;
 }
