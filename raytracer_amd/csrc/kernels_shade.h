@@ -190,7 +190,8 @@ __device__ __forceinline__ RGBd calculate_lighting(const SceneDev& sc, const Top
   d3 normal = is.n;
   // RTF:204; only the reflection direction and the specular term read it
   d3 surface_to_camera = rtx::mk(0.0, 0.0, 0.0);
-  if (REFLECT || has_material) surface_to_camera = rtx::normalize(rtx::sub(camera, surface_point));
+  // (the pixels-only instantiation normalizes it together with the first lights' directions, see below)
+  if ((REFLECT || has_material) && !INERT) surface_to_camera = rtx::normalize(rtx::sub(camera, surface_point));
 
   if constexpr (REFLECT) {  // RTF:207-224
     d3 incident = rtx::neg(surface_to_camera);
@@ -268,8 +269,19 @@ __device__ __forceinline__ RGBd calculate_lighting(const SceneDev& sc, const Top
     // divisions of a hit are most of its arithmetic and each is a chain of dependent instructions -- then the lights
     // are evaluated one after the other as the reference does.  (Doing the same for the three reflected-light
     // vectors of RTF:251 was measured slower: the reference has none for a light the surface faces away from.)
+    if (sc.n_lights > 0) {  // the first three lights, and the vector to the camera with them
+      d3 v[4], u[4];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) v[k] = rtx::sub(rtx::ld3(sc.lights[min(k, sc.n_lights - 1)].loc), surface_point);
+      v[3] = rtx::sub(camera, surface_point);
+      rtx::normalize_n<4>(v, u);
+      surface_to_camera = u[3];
+      one_light(0, u[0]);
+      if (1 < sc.n_lights) one_light(1, u[1]);
+      if (2 < sc.n_lights) one_light(2, u[2]);
+    }
 #pragma nounroll
-    for (int l0 = 0; l0 < sc.n_lights; l0 += 3) {
+    for (int l0 = 3; l0 < sc.n_lights; l0 += 3) {
       d3 v[3], ptl[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) v[k] = rtx::sub(rtx::ld3(sc.lights[min(l0 + k, sc.n_lights - 1)].loc), surface_point);

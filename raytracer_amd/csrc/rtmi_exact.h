@@ -59,26 +59,28 @@ RT_HD d3 normalize(d3 a) {
   }
   return mk(a.x / length, a.y / length, a.z / length);
 }
-// Three normalizations at once, each the same bits as normalize(): the three square roots and the three
-// divisions are written side by side, without a branch between them, so that their instruction sequences -- each a
-// chain of a dozen dependent operations -- can be issued interleaved.  The guard is checked once, afterwards;
-// in the rare case that it fails for any of the three, all are redone by normalize().
-RT_HD void normalize3(const d3 (&a)[3], d3 (&out)[3]) {
+// N normalizations at once, each the same bits as normalize(): the square roots and the divisions are written side
+// by side, without a branch between them, so that their instruction sequences -- each a chain of a dozen dependent
+// operations -- can be issued interleaved.  The guard is checked once, afterwards; in the rare case that it fails
+// for any of them, all are redone by normalize().
+template <int N>
+RT_HD void normalize_n(const d3 (&a)[N], d3 (&out)[N]) {
   const double lo = 3.054936363499605e-151, hi = 3.273390607896142e+150;  // 2^-500, 2^500
-  double length[3], r[3];
+  double length[N], r[N];
   bool ok = true;
-  for (int k = 0; k < 3; ++k) length[k] = sqrt(dp(a[k], a[k]));
-  for (int k = 0; k < 3; ++k) r[k] = 1.0 / length[k];
-  for (int k = 0; k < 3; ++k) {
+  for (int k = 0; k < N; ++k) length[k] = sqrt(dp(a[k], a[k]));
+  for (int k = 0; k < N; ++k) r[k] = 1.0 / length[k];
+  for (int k = 0; k < N; ++k) {
     const double qx = a[k].x * r[k], qy = a[k].y * r[k], qz = a[k].z * r[k];
     out[k] = mk(__builtin_fma(__builtin_fma(-qx, length[k], a[k].x), r[k], qx), __builtin_fma(__builtin_fma(-qy, length[k], a[k].y), r[k], qy),
                 __builtin_fma(__builtin_fma(-qz, length[k], a[k].z), r[k], qz));
     ok = ok && length[k] >= lo && length[k] <= hi && fabs(a[k].x) >= lo && fabs(a[k].y) >= lo && fabs(a[k].z) >= lo;
   }
   if (!ok) {
-    for (int k = 0; k < 3; ++k) out[k] = normalize(a[k]);
+    for (int k = 0; k < N; ++k) out[k] = normalize(a[k]);
   }
 }
+RT_HD void normalize3(const d3 (&a)[3], d3 (&out)[3]) { normalize_n<3>(a, out); }
 // cross, UTL:32-36
 RT_HD d3 cross(d3 a, d3 b) {
   return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
