@@ -244,9 +244,9 @@ k_search_exact(const SearchArgs* __restrict__ ap, int parity) {
     auto* tbits = as_global(reinterpret_cast<unsigned long long*>(ap->tval));
     constexpr bool nearest = NEAREST;
     const d3 o = rtx::ld3(ap->cam);
-    // The entry of the NEXT step is fetched (with the triangle index it leads to) before the
-    // current one is evaluated: a step begins with a chain of dependent loads, and this way the
-    // chain of step k+1 runs under the arithmetic of step k.
+    // A step begins with a chain of dependent loads: the entry, the triangle index it leads to, the triangle.
+    // They are spread over three steps -- this step's triangle, the next step's triangle index and the entry of the
+    // step after that are requested together -- so that a step waits for one memory latency instead of three.
     const int stride = parts * blockDim.x;
     const auto* group = as_global(ap->group);
     int i = part * blockDim.x + threadIdx.x;
@@ -258,23 +258,27 @@ k_search_exact(const SearchArgs* __restrict__ ap, int parity) {
       e.y = checked(e.y, n_group, wcnt, 7);
       return e;
     };
-    int2 c = i < n ? entry(i) : make_int2(0, 0);
+    int2 c = i < n ? entry(i) : make_int2(0, 0);             // this step's entry
+    int2 c1 = i + stride < n ? entry(i + stride) : c;        // the next step's
     int ti = i < n ? checked(group[c.y], n_tris, wcnt, 8) : 0;
     while (i < n) {
-      const int inext = i + stride;
-      const int2 cn = inext < n ? entry(inext) : c;
-      const int tin = checked(group[cn.y], n_tris, wcnt, 8);
+      const int i2 = i + 2 * stride;
       const int s = c.x, pos = c.y;
+      // requests of this step, none depending on another
       const auto* dp = dirs + (size_t)s * 3;
       const auto* tv0 = &tris[ti].v[0][0];  // nine doubles: the three vertices
       const auto* plp = planes + ti;
+      const double d0 = dp[0], d1 = dp[1], d2 = dp[2];
+      const double v0 = tv0[0], v1 = tv0[1], v2 = tv0[2], v3 = tv0[3], v4 = tv0[4], v5 = tv0[5], v6 = tv0[6], v7 = tv0[7], v8 = tv0[8];
       TriPlane pl;
       pl.nx = plp->nx; pl.ny = plp->ny; pl.nz = plp->nz; pl.c = plp->c;
+      const int ti1_raw = group[c1.y];
+      int2 c2 = c1;
+      if (i2 < n) c2 = cand[i2];
       d3 P;
       double tv;
       n_exact += 1;
-      if (rtx::tri_hit(rtx::mk(tv0[0], tv0[1], tv0[2]), rtx::mk(tv0[3], tv0[4], tv0[5]), rtx::mk(tv0[6], tv0[7], tv0[8]), pl, o,
-                       rtx::mk(dp[0], dp[1], dp[2]), &tv, &P)) {
+      if (rtx::tri_hit(rtx::mk(v0, v1, v2), rtx::mk(v3, v4, v5), rtx::mk(v6, v7, v8), pl, o, rtx::mk(d0, d1, d2), &tv, &P)) {
         if (nearest) {  // t > 0: the bit patterns of positive doubles order like the values
           atomicMin((unsigned long long*)&tbits[s], f64_bits(tv));
           cand[i].y = pos | NEAR_MARK;
@@ -282,9 +286,14 @@ k_search_exact(const SearchArgs* __restrict__ ap, int parity) {
           atomicMin((int*)&best_pos[s], pos);
         }
       }
-      c = cn;
-      ti = tin;
-      i = inext;
+      if (i2 < n) {
+        c2.x = checked(c2.x, n_samples, wcnt, 6);
+        c2.y = checked(c2.y, n_group, wcnt, 7);
+      }
+      ti = checked(ti1_raw, n_tris, wcnt, 8);
+      c = c1;
+      c1 = c2;
+      i += stride;
     }
   }
   wave_count(ap->cnt, C_EXACT, (unsigned long long)n_exact);
