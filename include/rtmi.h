@@ -149,6 +149,24 @@ typedef struct {
  * same with and without the flag. */
 #define RTMI_FLAG_NO_RAY_STATISTICS 1
 
+/* Two extensions to the shadow test, both off by default and NOT the reference's behaviour
+ * (RayTracingFunctions.swift:234-243 traces a shadow ray against the top-level list only and lets every
+ * intersection of a non-bounding object block the light, wherever it lies along the ray):
+ * RTMI_FLAG_SHADOW_MAX_DISTANCE    an intersection blocks the light only if its parameter is smaller than the
+ *                                  distance from the surface point to the light -- sqrt(lenSquared(light.location -
+ *                                  surfacePoint)), the length normalize() divides by at :227 -- so an object behind
+ *                                  the light (or a light placed in `objects` at its own location) casts no shadow;
+ * RTMI_FLAG_SHADOWS_ENTER_BOUNDED  a shadow ray that intersects a bounding sphere is traced against the sphere's
+ *                                  children as well, and a child that is hit blocks the light: the reference's own
+ *                                  "TODO seems like I'm forgetting to intersect with shapes inside the bounding
+ *                                  shape" (:240).  Reflection rays are unchanged.
+ * With either flag the hits of a frame are shaded by one general kernel after the search (no rays are left out:
+ * RTMI_FLAG_NO_RAY_STATISTICS has no effect), and rtmi_render_device_noalloc refuses the frame
+ * (RTMI_ERR_UNSUPPORTED).  RTMI_FLAG_SHADOWS_ENTER_BOUNDED needs every triangle to be listed by at most one
+ * object (else RTMI_ERR_UNSUPPORTED). */
+#define RTMI_FLAG_SHADOW_MAX_DISTANCE 2
+#define RTMI_FLAG_SHADOWS_ENTER_BOUNDED 4
+
 /* Work and timing counters of one render call. */
 typedef struct {
   int64_t samples;          /* primary rays generated                                    */

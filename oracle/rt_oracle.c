@@ -269,8 +269,14 @@ typedef struct {
 /* Hit policy: RTMI_HIT_LIST_ORDER is the reference (intersections[0], RTF:83, :93, :216).  RTMI_HIT_NEAREST is an
  * extension: at those three places the intersection with the smallest `parameter` is taken instead, the first in
  * list order among equal parameters.  Shadow rays (RTF:236-243: is anything hit at all) are the same in both. */
+/* Shadow-ray extensions (both off in the reference; they only act on the any_non_bounding question):
+ * max_t -- RTMI_FLAG_SHADOW_MAX_DISTANCE: an intersection only blocks the light if its parameter is below max_t, the
+ *          distance from the surface point to the light (INFINITY: the reference, RTF:236-243, where anything ahead of
+ *          the surface point blocks, however far behind the light it lies);
+ * enter -- RTMI_FLAG_SHADOWS_ENTER_BOUNDED: a bounding sphere the ray intersects has its children tested, and a child
+ *          that is hit blocks the light (the reference's own TODO at RTF:240). */
 static int trace_top(const rtmi_scene_desc* s, const list_stats* ls, v3 o, v3 d, isect* first,
-                     int* any_non_bounding, tally* tl, int nearest) {
+                     int* any_non_bounding, tally* tl, int nearest, double max_t, int enter) {
   double oo[3], dd[3];
   store(oo, o);
   store(dd, d);
@@ -287,7 +293,17 @@ static int trace_top(const rtmi_scene_desc* s, const list_stats* ls, v3 o, v3 d,
         double t[2], P[2][3], n[2][3];
         int32_t c = oracle_sphere_intersections(ob->center, ob->radius, oo, dd, t, P, n);
         if (c > 0) {
-          if (ob->kind == RTMI_SPHERE) anb = 1;
+          if (ob->kind == RTMI_SPHERE && t[0] < max_t) anb = 1; /* t[0] is the smallest root that was appended */
+          if (ob->kind == RTMI_BOUNDING_SPHERE && enter && any_non_bounding && !anb) {
+            tl->tri_tests += ob->count;
+            for (int64_t i = ob->first; i < ob->first + ob->count; ++i) {
+              double tc, Pc[3], nc[3];
+              if (oracle_triangle_intersection(s->triangles[i].v, oo, dd, &tc, Pc, nc) && tc < max_t) {
+                anb = 1;
+                break;
+              }
+            }
+          }
           if (!found || (nearest && t[0] < first->t)) { /* a sphere's own roots are sorted near first (REN:265-271) */
             found = 1;
             first->point = V(P[0]);
@@ -306,7 +322,7 @@ static int trace_top(const rtmi_scene_desc* s, const list_stats* ls, v3 o, v3 d,
         for (int64_t i = ob->first; i < ob->first + ob->count; ++i) {
           double t, P[3], n[3];
           if (oracle_triangle_intersection(s->triangles[i].v, oo, dd, &t, P, n)) {
-            anb = 1;
+            if (t < max_t) anb = 1;
             if (!found || (nearest && t < first->t)) {
               found = 1;
               first->point = V(P);
@@ -318,7 +334,8 @@ static int trace_top(const rtmi_scene_desc* s, const list_stats* ls, v3 o, v3 d,
               first->object = k;
               first->triangle = i;
             }
-            if (!nearest || any_non_bounding) break; /* later triangles of the run cannot change [0] or the any-flag */
+            /* later triangles of the run cannot change [0]; a shadow ray goes on until something blocks */
+            if (any_non_bounding ? anb : !nearest) break;
           }
         }
         break;
@@ -326,7 +343,7 @@ static int trace_top(const rtmi_scene_desc* s, const list_stats* ls, v3 o, v3 d,
       case RTMI_LIGHT: {
         double t, P[3];
         if (oracle_light_intersection(s->lights[ob->first].loc, oo, dd, &t, P)) {
-          anb = 1;
+          if (t < max_t) anb = 1;
           if (!found || (nearest && t < first->t)) {
             found = 1;
             first->point = V(P);
@@ -379,7 +396,7 @@ typedef struct { double r, g, b; } rgb;
 
 /* calculateLighting, RTF:182-271. */
 static rgb calculate_lighting(const rtmi_scene_desc* s, const list_stats* ls, const isect* is,
-                              const double ambient[3], v3 camera, int reflect, tally* tl, int nearest) {
+                              const double ambient[3], v3 camera, int reflect, tally* tl, int nearest, int flags) {
   v3 surface_point = is->point;
   const rtmi_material* material = is->material >= 0 ? &s->materials[is->material] : NULL;
 
@@ -400,8 +417,8 @@ static rgb calculate_lighting(const rtmi_scene_desc* s, const list_stats* ls, co
     rgb contribution = {0.0, 0.0, 0.0};
     isect rh;
     tl->rays_reflection += 1;
-    if (trace_top(s, ls, surface_point, reflection, &rh, NULL, tl, nearest)) {
-      contribution = calculate_lighting(s, ls, &rh, ambient, surface_point, 0, tl, nearest);
+    if (trace_top(s, ls, surface_point, reflection, &rh, NULL, tl, nearest, INFINITY, 0)) {
+      contribution = calculate_lighting(s, ls, &rh, ambient, surface_point, 0, tl, nearest, flags);
     }
     I.r = I.r + contribution.r;
     I.g = I.g + contribution.g;
@@ -410,13 +427,17 @@ static rgb calculate_lighting(const rtmi_scene_desc* s, const list_stats* ls, co
 
   for (int32_t li = 0; li < s->n_lights; ++li) { /* RTF:226-268 */
     const rtmi_light* light = &s->lights[li];
-    v3 point_to_light = normalize(sub(V(light->loc), surface_point));
+    v3 to_light = sub(V(light->loc), surface_point);
+    v3 point_to_light = normalize(to_light);
     double ndl = dp(point_to_light, normal);
     if (ndl <= 0) continue;
     isect dummy;
     int any_non_bounding = 0;
     tl->rays_shadow += 1;
-    trace_top(s, ls, surface_point, point_to_light, &dummy, &any_non_bounding, tl, nearest);
+    /* extension: the distance to the light, the length normalize() divided by (UTL:27-30) */
+    const double max_t = (flags & RTMI_FLAG_SHADOW_MAX_DISTANCE) ? sqrt(len_squared(to_light)) : INFINITY;
+    trace_top(s, ls, surface_point, point_to_light, &dummy, &any_non_bounding, tl, nearest, max_t,
+              (flags & RTMI_FLAG_SHADOWS_ENTER_BOUNDED) != 0);
     if (any_non_bounding) continue; /* RTF:241 */
     if (!material) continue;        /* RTF:245 */
     /* RTF:246-249 */
@@ -524,14 +545,14 @@ int32_t oracle_render(const rtmi_scene_desc* s, const rtmi_camera* cam, const rt
           rgb value = {0.0, 0.0, 0.0}; /* RGB.black, RTF:79,90 */
           int32_t id = -1;
           isect i1;
-          if (trace_top(s, &ls, camera, c2p, &i1, NULL, &tl, nearest)) { /* RTF:76-83 */
+          if (trace_top(s, &ls, camera, c2p, &i1, NULL, &tl, nearest, INFINITY, 0)) { /* RTF:76-83 */
             int have = 1;
             if (i1.is_bounding) { /* RTF:85-94 */
               have = trace_children(s, &s->objects[i1.object], i1.object, camera, c2p, &i1, &tl, nearest);
             }
             if (have) {
               tl.primary_hits += 1;
-              value = calculate_lighting(s, &ls, &i1, p->ambient, camera, 1, &tl, nearest); /* RTF:96 */
+              value = calculate_lighting(s, &ls, &i1, p->ambient, camera, 1, &tl, nearest, p->flags); /* RTF:96 */
               id = i1.triangle >= 0 ? (int32_t)i1.triangle : (int32_t)(-2 - i1.object);
             }
           }

@@ -272,7 +272,27 @@ def get_plane_vectors(direction):  # :46-57
     return u, v
 
 
-def calculate_lighting(isect, ambient_light, lights, camera, objects, reflect=True, counters=None, nearest=False):  # :182-271
+def shadow_blockers(hits, origin, direction, light, max_distance, enter_bounded):
+    """What keeps a light from a surface point, out of traceRay's intersections for the shadow ray: in the reference
+    every intersection of a non-bounding object (:241).  Two extensions: enter_bounded adds the intersections of the
+    children of every bounding sphere the ray intersects (the TODO at :240); max_distance keeps only intersections
+    that lie before the light."""
+    found = list(hits)
+    if enter_bounded:
+        entered = []
+        for h in hits:
+            if h.object.isBounding and not any(h.object is e for e in entered):
+                entered.append(h.object)
+                trace_ray(origin, direction, h.object.getBoundedIntersectables(), found)
+    blockers = [h for h in found if not h.object.isBounding]
+    if max_distance:
+        distance = fsqrt(len_squared(light.location - origin))
+        blockers = [h for h in blockers if h.parameter < distance]
+    return blockers
+
+
+def calculate_lighting(isect, ambient_light, lights, camera, objects, reflect=True, counters=None, nearest=False,
+                       shadow_max_distance=False, shadows_enter_bounded=False):  # :182-271
     surface_point = isect.point
     material = isect.object.material
     intensity = RGB(0, 0, 0)
@@ -292,7 +312,8 @@ def calculate_lighting(isect, ambient_light, lights, camera, objects, reflect=Tr
             counters["rays_reflection"] += 1
         trace_ray(surface_point, reflection, objects, hits)
         if hits:
-            contribution = calculate_lighting(pick(hits, nearest), ambient_light, lights, surface_point, objects, False, counters, nearest)
+            contribution = calculate_lighting(pick(hits, nearest), ambient_light, lights, surface_point, objects, False, counters, nearest,
+                                              shadow_max_distance, shadows_enter_bounded)
         intensity.add(contribution)
     for light in lights:
         point_to_light = normalize(light.location - surface_point)
@@ -303,7 +324,7 @@ def calculate_lighting(isect, ambient_light, lights, camera, objects, reflect=Tr
         if counters is not None:
             counters["rays_shadow"] += 1
         trace_ray(surface_point, point_to_light, objects, hits)
-        if sum(1 for h in hits if not h.object.isBounding) > 0:
+        if len(shadow_blockers(hits, surface_point, point_to_light, light, shadow_max_distance, shadows_enter_bounded)) > 0:
             continue
         if material is not None:
             contribution = light.diffuse.copy()
@@ -362,7 +383,8 @@ def to_u8(c):
     return int(255 * c)
 
 
-def raytrace_world(camera, camera_direction, focal_length, width, height, subdivision, ambient, lights, objects, nearest=False):
+def raytrace_world(camera, camera_direction, focal_length, width, height, subdivision, ambient, lights, objects, nearest=False,
+                   shadow_max_distance=False, shadows_enter_bounded=False):
     """raytraceWorld + raytracePixels (:145-180, :59-114) with the frame size and the subdivision as arguments.
     Returns (rgba rows as nested lists [H][W][4] or None where nothing is written, hit ids [H][W][spp], counters)."""
     center = camera + camera_direction.times(focal_length)
@@ -397,7 +419,8 @@ def raytrace_world(camera, camera_direction, focal_length, width, height, subdiv
                     continue
                 i1 = pick(inner, nearest)
             counters["primary_hits"] += 1
-            values.append(calculate_lighting(i1, ambient, lights, camera, objects, True, counters, nearest))
+            values.append(calculate_lighting(i1, ambient, lights, camera, objects, True, counters, nearest,
+                                             shadow_max_distance, shadows_enter_bounded))
             ids.append(i1.object.ident)
         avg = average(values)
         rgba[y][x] = [to_u8(avg.red), to_u8(avg.green), to_u8(avg.blue), 255]
@@ -446,7 +469,8 @@ def render(data, camera, params):
     lights, objects = build_scene(data)
     amb = RGB(*[float(x) for x in params.ambient])
     return raytrace_world(V3(*camera.pos), V3(*camera.dir), float(camera.focal_length), params.width, params.height,
-                          float(params.pixel_subdivision), amb, lights, objects, nearest=params.hit_policy == 1)
+                          float(params.pixel_subdivision), amb, lights, objects, nearest=params.hit_policy == 1,
+                          shadow_max_distance=bool(params.flags & 2), shadows_enter_bounded=bool(params.flags & 4))
 
 
 # ---- ObjLoader.swift, ViewController.swift:107-120 ----------------------------------------------

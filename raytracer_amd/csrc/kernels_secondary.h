@@ -82,6 +82,19 @@ __device__ inline TopTreeRef make_top_tree(const TopTreeArgs& a, const f2* rec, 
   return t;
 }
 
+// The shadow-ray extensions (RTMI_FLAG_SHADOW_MAX_DISTANCE, RTMI_FLAG_SHADOWS_ENTER_BOUNDED) walk trees of the same
+// layout over other member lists, with two more conditions on a hit.  members/n_members/c0 replace
+// SceneDev::top_group/n_top_tris/c0; a hit counts only below max_t; with member_owner (member -> the bounding
+// sphere that lists it) a hit counts only if the ray intersects that sphere at all, which is when the
+// extension tests the sphere's children.
+struct WalkExt {
+  const int* members;       // member ordinal -> triangle index
+  const int* member_owner;  // member ordinal -> object index of its bounding sphere, or nullptr
+  long long n_members;
+  double c0[3];
+  double max_t;
+};
+
 // A general-origin ray (reflection or shadow ray) against ALL top-level triangles: the ordinal of
 // the hit that comes first in list order (any_only: of some hit), or -1.  The lanes that call this
 // together walk the tree together, like k_search_tree: a record of eight bounding spheres is
@@ -89,9 +102,14 @@ __device__ inline TopTreeRef make_top_tree(const TopTreeArgs& a, const f2* rec, 
 // instruction), and a child is entered if some lane passes.  At a leaf the per-triangle cascade
 // of k_pack_general follows, then rtx::tri_hit in FP64.  Called from divergent shading code: the
 // wave-level votes only see the lanes that are tracing.
+// EXT: the tree and the conditions of *WX (see WalkExt); any_only walks only.
+template <bool EXT = false>
 __device__ inline int top_tree_trace(const SceneDev& sc, const TopTreeRef& T, d3 o, d3 d, bool any_only, double* t_out,
-                                     d3* P_out, tally_t* n_tests) {
-  const float ox = (float)(o.x - sc.c0[0]), oy = (float)(o.y - sc.c0[1]), oz = (float)(o.z - sc.c0[2]);
+                                     d3* P_out, tally_t* n_tests, const WalkExt* WX = nullptr) {
+  const double c0x = EXT ? WX->c0[0] : sc.c0[0], c0y = EXT ? WX->c0[1] : sc.c0[1], c0z = EXT ? WX->c0[2] : sc.c0[2];
+  const long long n_members = EXT ? WX->n_members : sc.n_top_tris;
+  const int* members = EXT ? WX->members : sc.top_group;
+  const float ox = (float)(o.x - c0x), oy = (float)(o.y - c0y), oz = (float)(o.z - c0z);
   const float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
   const float ndo = -(dx * ox + dy * oy + dz * oz);
   const float noo = -(ox * ox + oy * oy + oz * oz);
@@ -161,7 +179,7 @@ __device__ inline int top_tree_trace(const SceneDev& sc, const TopTreeRef& T, d3
         unsigned long long cm = live_m & wave_mask(!(u < 0.0f));
         if (!cm) continue;
         const int g = T.slot_pos[ri * 8 + pr * 2 + h];  // top-level ordinal
-        if ((unsigned)g >= (unsigned)sc.n_top_tris) continue;  // padding slot (its sphere passes nothing; belt and braces)
+        if ((unsigned)g >= (unsigned)n_members) continue;  // padding slot (its sphere passes nothing; belt and braces)
         // a later list position cannot replace the hit
         cand = cand && (any_only ? best == 0x7fffffff : g < best);
         cm &= any_only ? wave_mask(best == 0x7fffffff) : wave_mask(g < best);
@@ -185,11 +203,19 @@ __device__ inline int top_tree_trace(const SceneDev& sc, const TopTreeRef& T, d3
         }
         if (!cm) continue;
         if (cand) {
-          const int ti = min(max(sc.top_group[g], 0), sc.n_tris - 1);  // the clamps never bind
+          const int ti = min(max(members[g], 0), sc.n_tris - 1);  // the clamps never bind
           const rtmi_triangle& tr = sc.tris[ti];
           double t;
           d3 P;
-          if (rtx::tri_hit(rtx::ld3(tr.v[0]), rtx::ld3(tr.v[1]), rtx::ld3(tr.v[2]), sc.planes[ti], o, d, &t, &P)) {
+          bool hit = rtx::tri_hit(rtx::ld3(tr.v[0]), rtx::ld3(tr.v[1]), rtx::ld3(tr.v[2]), sc.planes[ti], o, d, &t, &P);
+          if constexpr (EXT) {
+            hit = hit && t < WX->max_t;
+            if (hit && WX->member_owner) {
+              const rtmi_object& ob = sc.objects[min(max(WX->member_owner[g], 0), sc.n_objects - 1)];
+              hit = rtx::sphere_any(rtx::ld3(ob.center), ob.radius, o, d);
+            }
+          }
+          if (hit) {
             best = g;
             *t_out = t;
             *P_out = P;
@@ -520,4 +546,63 @@ __device__ inline bool trace_top_secondary_nearest(const SceneDev& sc, const Top
   }
   *any_non_bounding = anb;
   return found;
+}
+
+// ---------------------------------------------------------------------------------------
+// shadow-ray extensions (RTMI_FLAG_SHADOW_MAX_DISTANCE, RTMI_FLAG_SHADOWS_ENTER_BOUNDED)
+// ---------------------------------------------------------------------------------------
+// The scalar part of what the extensions add to a shading launch: the flags and a second bounding-sphere tree,
+// over the children of ALL bounding spheres of the scene (built when a frame first asks for
+// RTMI_FLAG_SHADOWS_ENTER_BOUNDED; same layout as the tree of the top-level runs).
+struct ExtArgs {
+  int flags;             // RTMI_FLAG_SHADOW_MAX_DISTANCE | RTMI_FLAG_SHADOWS_ENTER_BOUNDED
+  int pad;
+  long long n_bounded;   // members of the bounded tree (0: none, or the flag is off)
+  double c0[3];          // centre its FP32 coordinates are relative to
+  TopTreeArgs tree;
+};
+
+struct ExtRef {
+  int flags;
+  TopTreeRef bounded;       // tree over the bounded children
+  const int* members;       // member ordinal -> triangle index
+  const int* member_owner;  // member ordinal -> object index of its bounding sphere
+  long long n_bounded;
+  double c0[3];
+};
+
+// The shadow test RTF:236-243 with the extensions: does anything other than a bounding sphere intersect the
+// ray at a parameter below max_t (INFINITY without RTMI_FLAG_SHADOW_MAX_DISTANCE), counting -- with
+// RTMI_FLAG_SHADOWS_ENTER_BOUNDED -- the children of every bounding sphere the ray intersects.
+__device__ inline bool shadow_blocked_ext(const SceneDev& sc, const TopTreeRef& tt, const ExtRef& ext, d3 o, d3 d, double max_t,
+                                          tally_t* n_tests) {
+#pragma nounroll
+  for (int k = 0; k < sc.n_objects; ++k) {
+    const rtmi_object& ob = sc.objects[k];
+    double t;
+    d3 P, n;
+    if (ob.kind == RTMI_SPHERE) {
+      // the smallest root Sphere.intersections appends (REN:265-271): if that one is not below max_t, none is
+      if (rtx::sphere_first_raw(rtx::ld3(ob.center), ob.radius, o, d, &t, &P, &n) && t < max_t) return true;
+    } else if (ob.kind == RTMI_LIGHT) {
+      if (rtx::light_hit(rtx::ld3(sc.lights[ob.first].loc), o, d, &t, &P) && t < max_t) return true;
+    }
+  }
+  double t;
+  d3 P;
+  if (sc.n_top_tris > 0) {
+    WalkExt w;
+    w.members = sc.top_group; w.member_owner = nullptr; w.n_members = sc.n_top_tris;
+    w.c0[0] = sc.c0[0]; w.c0[1] = sc.c0[1]; w.c0[2] = sc.c0[2];
+    w.max_t = max_t;
+    if (top_tree_trace<true>(sc, tt, o, d, true, &t, &P, n_tests, &w) >= 0) return true;
+  }
+  if ((ext.flags & RTMI_FLAG_SHADOWS_ENTER_BOUNDED) && ext.n_bounded > 0) {
+    WalkExt w;
+    w.members = ext.members; w.member_owner = ext.member_owner; w.n_members = ext.n_bounded;
+    w.c0[0] = ext.c0[0]; w.c0[1] = ext.c0[1]; w.c0[2] = ext.c0[2];
+    w.max_t = max_t;
+    if (top_tree_trace<true>(sc, ext.bounded, o, d, true, &t, &P, n_tests, &w) >= 0) return true;
+  }
+  return false;
 }

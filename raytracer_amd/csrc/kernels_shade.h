@@ -158,10 +158,14 @@ __device__ __forceinline__ bool traced_any(const SceneDev& sc, const TopTreeRef&
 // changes a pixel -- a bounding sphere blocks no light (RTF:241) and, lacking a material, reflects none
 // (RTF:192, :245) -- so the rays are neither traced nor counted (the caller asked for pixels, not for the
 // reference's ray statistics: RTMI_FLAG_NO_RAY_STATISTICS).
-template <bool REFLECT, bool HAS_TOP, bool LEAN = false, bool INERT = false, bool NEAREST = false, int MODE = TRACE_LIVE>
+// EXT (with neither LEAN nor INERT, MODE TRACE_LIVE): the shadow test of the light loop follows *ext
+// (RTMI_FLAG_SHADOW_MAX_DISTANCE, RTMI_FLAG_SHADOWS_ENTER_BOUNDED; shadow_blocked_ext) instead of RTF:236-243.
+template <bool REFLECT, bool HAS_TOP, bool LEAN = false, bool INERT = false, bool NEAREST = false, int MODE = TRACE_LIVE,
+          bool EXT = false>
 __device__ __forceinline__ RGBd calculate_lighting(const SceneDev& sc, const TopTreeRef& tt, const ShadeConst& fc, const Hit& is, d3 camera,
                                    tally_t* n_refl, tally_t* n_shadow, tally_t* n_tests, tally_t* n_elided, bool* defer = nullptr,
-                                   TraceRec* rec = nullptr) {
+                                   TraceRec* rec = nullptr, const ExtRef* ext = nullptr) {
+  static_assert(!EXT || (!LEAN && !INERT && MODE == TRACE_LIVE), "the extensions run in the general instantiation only");
   d3 surface_point = is.P;
   RGBd I = {0.0, 0.0, 0.0};
   const bool has_material = is.material >= 0;
@@ -219,8 +223,8 @@ __device__ __forceinline__ RGBd calculate_lighting(const SceneDev& sc, const Top
     } else {
       *n_refl += 1;
       if (traced_first<MODE, HAS_TOP, NEAREST>(sc, tt, surface_point, reflection, &rh, n_tests, rec)) {
-        contribution = calculate_lighting<false, HAS_TOP, false, false, NEAREST, MODE>(sc, tt, fc, rh, surface_point, n_refl, n_shadow,
-                                                                                       n_tests, n_elided, nullptr, rec);
+        contribution = calculate_lighting<false, HAS_TOP, false, false, NEAREST, MODE, EXT>(sc, tt, fc, rh, surface_point, n_refl,
+                                                                                            n_shadow, n_tests, n_elided, nullptr, rec, ext);
       }
     }
     I.r = I.r + contribution.r;
@@ -244,7 +248,14 @@ __device__ __forceinline__ RGBd calculate_lighting(const SceneDev& sc, const Top
     const rtmi_light& light = sc.lights[li];
     double ndl = rtx::dp(point_to_light, normal);
     if (ndl <= 0) return;
-    if constexpr (!INERT) {
+    if constexpr (EXT) {
+      *n_shadow += 1;
+      // the distance to the light: the length normalize() divided by at RTF:227 (UTL:27-30)
+      const double max_t = (ext->flags & RTMI_FLAG_SHADOW_MAX_DISTANCE)
+                               ? sqrt(rtx::len_squared(rtx::sub(rtx::ld3(light.loc), surface_point)))
+                               : INFINITY;
+      if (shadow_blocked_ext(sc, tt, *ext, surface_point, point_to_light, max_t, n_tests)) return;
+    } else if constexpr (!INERT) {
       *n_shadow += 1;
       if (traced_any<MODE, HAS_TOP, NEAREST>(sc, tt, surface_point, point_to_light, n_tests, rec, shadow_key(li, REFLECT ? 0 : 1)))
         return;  // RTF:241
@@ -351,9 +362,10 @@ __device__ __forceinline__ bool primary_hit(const SceneDev& sc, d3 cam, d3 d, in
 // t_tri is the triangle's intersection parameter.  LEAN: returns true, with nothing counted or stored,
 // if the sample needs the full instantiation (see calculate_lighting).
 // MODE (see TraceRec): TRACE_RECORD traces the sample's secondary rays into *rec and stores no colour.
-template <bool HAS_TOP, bool LEAN = false, bool NEAREST = false, int MODE = TRACE_LIVE>
+template <bool HAS_TOP, bool LEAN = false, bool NEAREST = false, int MODE = TRACE_LIVE, bool EXT = false>
 __device__ __forceinline__ bool shade_sample(const ShadeConst& fc, const SceneDev& sc, const TopTreeRef& tt, int s, d3 d,
-                                             int id, double t_tri, double* rgb, ShadeTally* tl, TraceRec* rec = nullptr) {
+                                             int id, double t_tri, double* rgb, ShadeTally* tl, TraceRec* rec = nullptr,
+                                             const ExtRef* ext = nullptr) {
   d3 cam = rtx::ld3(fc.cam);
   Hit h;
   const bool ok = primary_hit(sc, cam, d, id, t_tri, &h);
@@ -361,8 +373,8 @@ __device__ __forceinline__ bool shade_sample(const ShadeConst& fc, const SceneDe
   if (ok) {
     bool defer = false;
     static_assert(!LEAN, "the lean lighting needs a wave-uniform material: shade_triangle_lean");
-    c = calculate_lighting<true, HAS_TOP, false, false, NEAREST, MODE>(sc, tt, fc, h, cam, &tl->n_refl, &tl->n_shadow, &tl->n_tests,
-                                                                       &tl->n_elided, &defer, rec);
+    c = calculate_lighting<true, HAS_TOP, false, false, NEAREST, MODE, EXT>(sc, tt, fc, h, cam, &tl->n_refl, &tl->n_shadow, &tl->n_tests,
+                                                                            &tl->n_elided, &defer, rec, ext);
     tl->n_hit += 1;
   }
   if constexpr (MODE != TRACE_RECORD) {
@@ -418,6 +430,37 @@ k_shade(ShadeConst fc, SceneDev sc, TopTreeArgs ta, const f2* __restrict__ trec,
     if (id >= 0) id = checked(id, sc.n_tris, cnt, 18);
     else id = -2 - checked(-2 - id, sc.n_objects, cnt, 19);
     shade_sample<HAS_TOP, false, NEAREST>(fc, sc, tt, s, d, id, id >= 0 ? tval[s] : 0.0, rgb, &tl);
+  }
+  shade_tally_flush(cnt, tl);
+}
+
+// k_shade with the shadow-ray extensions: every hit of the frame comes through the shade queue (see
+// k_shade_candidates, QUEUE_ALL) and is shaded here by the general instantiation.  The top-level runs' tree is
+// walked if the scene has one (its root count is zero otherwise); b* are the bounded tree's arrays.
+template <bool NEAREST>
+__global__ void __launch_bounds__(256)
+k_shade_ext(ShadeConst fc, SceneDev sc, TopTreeArgs ta, const f2* __restrict__ trec, const float* __restrict__ gst2,
+            const int* __restrict__ tslot_pos, ExtArgs ea, const f2* __restrict__ brec, const float* __restrict__ bgst2,
+            const int* __restrict__ bslot_pos, const int* __restrict__ bmembers, const int* __restrict__ bowner,
+            const double* __restrict__ dirs, const double* __restrict__ tval, const int* __restrict__ q_shade,
+            const int* __restrict__ nq_ptr, const int* __restrict__ hit_id, double* rgb, DevCounters* cnt) {
+  const TopTreeRef tt = make_top_tree(ta, trec, gst2, tslot_pos);
+  ExtRef ext;
+  ext.flags = ea.flags;
+  ext.bounded = make_top_tree(ea.tree, brec, bgst2, bslot_pos);
+  ext.members = bmembers;
+  ext.member_owner = bowner;
+  ext.n_bounded = ea.n_bounded;
+  ext.c0[0] = ea.c0[0]; ext.c0[1] = ea.c0[1]; ext.c0[2] = ea.c0[2];
+  ShadeTally tl;
+  const int nq = *nq_ptr;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
+    int s = checked(q_shade[q], sc.n_samples, cnt, 32);
+    d3 d = rtx::mk(dirs[(size_t)s * 3 + 0], dirs[(size_t)s * 3 + 1], dirs[(size_t)s * 3 + 2]);
+    int id = hit_id[s];
+    if (id >= 0) id = checked(id, sc.n_tris, cnt, 33);
+    else id = -2 - checked(-2 - id, sc.n_objects, cnt, 34);
+    shade_sample<true, false, NEAREST, TRACE_LIVE, true>(fc, sc, tt, s, d, id, id >= 0 ? tval[s] : 0.0, rgb, &tl, nullptr, &ext);
   }
   shade_tally_flush(cnt, tl);
 }
@@ -491,7 +534,8 @@ k_shade_replay(ShadeConst fc, SceneDev sc, TopTreeArgs ta, const f2* __restrict_
 // Without top-level triangle runs the lean instantiation of the lighting runs here; the rare sample whose
 // reflected ray finds an object with a material goes to the shade queue (with its t), which k_shade serves
 // afterwards with the full instantiation.
-template <bool HAS_TOP, bool INERT = false, bool NEAREST = false>
+// QUEUE_ALL (with neither HAS_TOP nor INERT): nothing is shaded here; every intersection goes to the shade queue.
+template <bool HAS_TOP, bool INERT = false, bool NEAREST = false, bool QUEUE_ALL = false>
 __global__ void __launch_bounds__(256, HAS_TOP ? (NEAREST ? 1 : 2) : (INERT ? SHADE_INERT_WAVES : SHADE_LEAN_WAVES))
 k_shade_candidates(ShadeConst fc, SceneDev sc, TopTreeArgs ta, const f2* __restrict__ trec, const float* __restrict__ gst2,
                    const int* __restrict__ tslot_pos, const SearchArgs* __restrict__ ap, double* rgb, int par) {
@@ -539,7 +583,10 @@ k_shade_candidates(ShadeConst fc, SceneDev sc, TopTreeArgs ta, const f2* __restr
         tv = rtx::tri_t(sc.planes[ti], rtx::ld3(fc.cam), d);  // k_search_exact accepted this pair
         hit_id[s] = ti;
       }
-      if constexpr (HAS_TOP) {
+      if constexpr (QUEUE_ALL) {
+        static_assert(!QUEUE_ALL || (!HAS_TOP && !INERT), "QUEUE_ALL queues through the HAS_TOP == false path");
+        deferred = want;
+      } else if constexpr (HAS_TOP) {
         if (want) shade_sample<true, false, NEAREST>(fc, sc, tt, s, d, ti, tv, rgb, &tl);
       } else {
         if (want) deferred = shade_triangle_lean<INERT, NEAREST>(fc, sc, tt, s, d, ti, tv, rgb, &tl);

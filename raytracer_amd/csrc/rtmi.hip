@@ -239,6 +239,15 @@ struct rtmi_scene {
   float* d_trec = nullptr;      // bounding-sphere records of the top-level runs (secondary rays)
   float* d_gst2 = nullptr;      // their per-triangle plane and edge operands
   TopTreeArgs top_args{};
+  // RTMI_FLAG_SHADOWS_ENTER_BOUNDED: a second tree of the same kind over the children of all bounding spheres,
+  // built by the first frame that asks for it (ensure_bounded_tree)
+  bool bounded_tree_built = false;
+  int* d_bmembers = nullptr;    // member ordinal -> triangle index
+  int* d_bowner = nullptr;      // member ordinal -> object index of its bounding sphere
+  int* d_bslot_pos = nullptr;
+  float* d_brec = nullptr;
+  float* d_bgst2 = nullptr;
+  ExtArgs bounded_args{};       // tree, member count, coordinate centre (flags are set per frame)
   std::vector<TriGroup> groups;  // [0] = top-level runs (may be empty), then bounding objects
   SceneDev dev{};
   // per-batch work buffers: the scene's own (grown on demand), or for the duration of one
@@ -434,6 +443,8 @@ extern "C" void rtmi_scene_destroy(rtmi_scene* sc) {
   (void)hipFree(sc->d_objects); (void)hipFree(sc->d_lights); (void)hipFree(sc->d_materials);
   (void)hipFree(sc->d_tris); (void)hipFree(sc->d_planes); (void)hipFree(sc->d_tri_owner);
   (void)hipFree(sc->d_trec); (void)hipFree(sc->d_gst2);
+  (void)hipFree(sc->d_bmembers); (void)hipFree(sc->d_bowner); (void)hipFree(sc->d_bslot_pos);
+  (void)hipFree(sc->d_brec); (void)hipFree(sc->d_bgst2);
   (void)hipFree(sc->wb.hit_id); (void)hipFree(sc->wb.tri_hit); (void)hipFree(sc->wb.q_child);
   (void)hipFree(sc->wb.q_shade); (void)hipFree(sc->wb.q_top); (void)hipFree(sc->wb.rgb);
   (void)hipFree(sc->wb.dirs); (void)hipFree(sc->wb.tval); (void)hipFree(sc->wb.best_pos); (void)hipFree(sc->wb.cand); (void)hipFree(sc->wb.tabs); (void)hipFree(sc->d_sargs); (void)hipFree(sc->d_genf);
@@ -446,6 +457,39 @@ extern "C" void rtmi_scene_destroy(rtmi_scene* sc) {
   if (sc->ev_d) (void)hipEventDestroy(sc->ev_d);
   if (sc->stream) (void)hipStreamDestroy(sc->stream);
   delete sc;
+}
+
+// The frame of reference of a general-origin filter over the triangles `members`: c0 = the centre of their
+// bounding box (FP32 coordinates are taken relative to it) and r_o1, a bound on |o - c0|_1 over every point a
+// secondary ray can start from -- all triangles, spheres and lights listed as objects.
+static void general_frame(const rtmi_triangle* tris, int64_t n_tris, const rtmi_object* objects, int64_t n_objects,
+                          const rtmi_light* lights, const std::vector<int>& members, double c0[3], double* r_o1_out) {
+  double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  double slo[3] = {INFINITY, INFINITY, INFINITY}, shi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  auto grow = [](double* l, double* h, const double* p, double r) {
+    // non-finite coordinates (such triangles are never hit) must not reach the FP32 frame of reference
+    if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2]) || !std::isfinite(r)) return;
+    for (int a = 0; a < 3; ++a) { l[a] = std::min(l[a], p[a] - r); h[a] = std::max(h[a], p[a] + r); }
+  };
+  for (int ti : members) for (int k = 0; k < 3; ++k) grow(lo, hi, tris[ti].v[k], 0.0);
+  // every surface a ray can start from: all triangles, spheres, lights listed as objects
+  for (int64_t i = 0; i < n_tris; ++i) for (int k = 0; k < 3; ++k) grow(slo, shi, tris[i].v[k], 0.0);
+  for (int64_t k = 0; k < n_objects; ++k) {
+    const rtmi_object& ob = objects[k];
+    if (ob.kind == RTMI_SPHERE || ob.kind == RTMI_BOUNDING_SPHERE) grow(slo, shi, ob.center, fabs(ob.radius));
+    else if (ob.kind == RTMI_LIGHT) grow(slo, shi, lights[ob.first].loc, 0.0);
+  }
+  double r_o1 = 0.0;
+  for (int a = 0; a < 3; ++a) {
+    c0[a] = 0.5 * (lo[a] + hi[a]);
+    r_o1 += std::max(fabs(slo[a] - c0[a]), fabs(shi[a] - c0[a]));
+  }
+  r_o1 *= 1.01;
+  if (!std::isfinite(r_o1)) {  // no finite point at all: the filters then degrade to "always nominate" via their own checks
+    r_o1 = 0.0;
+    c0[0] = c0[1] = c0[2] = 0.0;
+  }
+  *r_o1_out = r_o1;
 }
 
 static int32_t scene_create_impl(const rtmi_scene_desc* desc, int32_t device, rtmi_scene* sc) {
@@ -556,31 +600,8 @@ static int32_t scene_create_impl(const rtmi_scene_desc* desc, int32_t device, rt
   // general-origin filter for secondary rays against the top-level triangle runs
   double c0[3] = {0.0, 0.0, 0.0};
   if (!top.empty()) {
-    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    double slo[3] = {INFINITY, INFINITY, INFINITY}, shi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    auto grow = [](double* l, double* h, const double* p, double r) {
-      // non-finite coordinates (such triangles are never hit) must not reach the FP32 frame of reference
-      if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2]) || !std::isfinite(r)) return;
-      for (int a = 0; a < 3; ++a) { l[a] = std::min(l[a], p[a] - r); h[a] = std::max(h[a], p[a] + r); }
-    };
-    for (int ti : top) for (int k = 0; k < 3; ++k) grow(lo, hi, desc->triangles[ti].v[k], 0.0);
-    // every surface a ray can start from: all triangles, spheres, lights listed as objects
-    for (int64_t i = 0; i < desc->n_triangles; ++i) for (int k = 0; k < 3; ++k) grow(slo, shi, desc->triangles[i].v[k], 0.0);
-    for (int64_t k = 0; k < desc->n_objects; ++k) {
-      const rtmi_object& ob = desc->objects[k];
-      if (ob.kind == RTMI_SPHERE || ob.kind == RTMI_BOUNDING_SPHERE) grow(slo, shi, ob.center, fabs(ob.radius));
-      else if (ob.kind == RTMI_LIGHT) grow(slo, shi, desc->lights[ob.first].loc, 0.0);
-    }
     double r_o1 = 0.0;
-    for (int a = 0; a < 3; ++a) {
-      c0[a] = 0.5 * (lo[a] + hi[a]);
-      r_o1 += std::max(fabs(slo[a] - c0[a]), fabs(shi[a] - c0[a]));
-    }
-    r_o1 *= 1.01;
-    if (!std::isfinite(r_o1)) {  // no finite point at all: the filters then degrade to "always nominate" via their own checks
-      r_o1 = 0.0;
-      c0[0] = c0[1] = c0[2] = 0.0;
-    }
+    general_frame(desc->triangles, desc->n_triangles, desc->objects, desc->n_objects, desc->lights, top, c0, &r_o1);
     const size_t nt = top.size();
     HIP_TRY(hipMalloc(&sc->d_gst2, sizeof(float) * GST2_FLOATS * nt));
     hipLaunchKernelGGL(k_pack_general, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, sc->stream, sc->d_tris,
@@ -723,6 +744,63 @@ static int32_t pack_group(rtmi_scene* sc, TriGroup& g, d3 cam) {
 // record fetches whatever the number of rays it carries, and a small batch (a 1080p frame at 4 samples per pixel is
 // 8 M samples) has too few waves at 4 rays per lane to hide that chain -- measured on the 1.3 M-triangle mesh at
 // 1080p: 1.40 ms per frame with 2 rays per lane, 1.67 with 4; at 4K and 16 samples per pixel 4 wins by 11 %.
+// RTMI_FLAG_SHADOWS_ENTER_BOUNDED: the bounding-sphere tree over the children of all bounding spheres (the same
+// construction as the top-level runs' tree in scene_create_impl), built when a frame first asks for the flag.
+// The triangles come back from the device: the caller's arrays are gone by now.  The scene's stream is idle.
+static int32_t ensure_bounded_tree(rtmi_scene* sc) {
+  if (sc->bounded_tree_built) return RTMI_OK;
+  std::vector<int> members, owner;
+  for (size_t k = 0; k < sc->objects.size(); ++k) {
+    const rtmi_object& ob = sc->objects[k];
+    if (ob.kind != RTMI_BOUNDING_SPHERE) continue;
+    if (members.size() + (size_t)ob.count > 0x7ffffff0ull) return RTMI_ERR_UNSUPPORTED;
+    for (int64_t i = ob.first; i < ob.first + ob.count; ++i) {
+      members.push_back((int)i);
+      owner.push_back((int)k);
+    }
+  }
+  ExtArgs args{};
+  if (!members.empty()) {
+    HIP_TRY(hipStreamSynchronize(sc->stream));
+    std::vector<rtmi_triangle> tris((size_t)sc->n_tris);
+    HIP_TRY(hipMemcpy(tris.data(), sc->d_tris, sizeof(rtmi_triangle) * tris.size(), hipMemcpyDeviceToHost));
+    double c0[3] = {0.0, 0.0, 0.0}, r_o1 = 0.0;
+    general_frame(tris.data(), sc->n_tris, sc->objects.data(), (int64_t)sc->objects.size(), sc->h_lights.data(), members, c0, &r_o1);
+    TreeHost th;
+    tree_build_host(tris.data(), members, &th);
+    auto upload = [&](void** dst, const void* src, size_t bytes) -> int32_t {
+      HIP_TRY(hipMalloc(dst, bytes));
+      HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+      return RTMI_OK;
+    };
+    int32_t rc;
+    const size_t nm = members.size();
+    if ((rc = upload((void**)&sc->d_bmembers, members.data(), sizeof(int) * nm))) return rc;
+    if ((rc = upload((void**)&sc->d_bowner, owner.data(), sizeof(int) * nm))) return rc;
+    if ((rc = upload((void**)&sc->d_bslot_pos, th.slot_pos.data(), sizeof(int) * th.slot_pos.size()))) return rc;
+    HIP_TRY(hipMalloc(&sc->d_bgst2, sizeof(float) * GST2_FLOATS * nm));
+    hipLaunchKernelGGL(k_pack_general, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, sc->stream, sc->d_tris,
+                       sc->d_bmembers, (int)nm, rtx::mk(c0[0], c0[1], c0[2]), r_o1, sc->d_bgst2);
+    HIP_TRY(hipGetLastError());
+    std::vector<float> trec;
+    unsigned cone_levels = 0;
+    tree_sphere_records(tris.data(), th, c0, r_o1, &trec, &cone_levels);
+    if ((rc = upload((void**)&sc->d_brec, trec.data(), sizeof(float) * trec.size()))) return rc;
+    args.tree.cone_levels = normal_cones_enabled() ? (int)cone_levels : 0;
+    args.tree.ltop = th.dev.ltop;
+    args.tree.n_root = th.dev.n_root;
+    args.tree.n_slots = th.dev.n_slots;
+    args.tree.n_records = (int)th.n_records;
+    for (int l = 0; l < TREE_MAX_LEVELS; ++l) args.tree.off[l] = th.dev.rec_off[l];
+    args.n_bounded = (long long)nm;
+    for (int a = 0; a < 3; ++a) args.c0[a] = c0[a];
+    HIP_TRY(hipStreamSynchronize(sc->stream));
+  }
+  sc->bounded_args = args;
+  sc->bounded_tree_built = true;
+  return RTMI_OK;
+}
+
 static int search_rays_per_lane(bool tree, int nsamples) {
   static int forced = [] {
     const char* e = getenv("RTMI_SEARCH_R");
@@ -769,7 +847,15 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
   }
   if (p->hit_policy != RTMI_HIT_LIST_ORDER && p->hit_policy != RTMI_HIT_NEAREST) return RTMI_ERR_UNSUPPORTED;
   if (p->search != RTMI_SEARCH_CONE_TREE && p->search != RTMI_SEARCH_LIST_SCAN) return RTMI_ERR_INVALID_ARGUMENT;
-  if (p->flags & ~RTMI_FLAG_NO_RAY_STATISTICS) return RTMI_ERR_INVALID_ARGUMENT;
+  if (p->flags & ~(RTMI_FLAG_NO_RAY_STATISTICS | RTMI_FLAG_SHADOW_MAX_DISTANCE | RTMI_FLAG_SHADOWS_ENTER_BOUNDED))
+    return RTMI_ERR_INVALID_ARGUMENT;
+  // the shadow-ray extensions: every hit is shaded from the shade queue by k_shade_ext
+  const int ext_flags = p->flags & (RTMI_FLAG_SHADOW_MAX_DISTANCE | RTMI_FLAG_SHADOWS_ENTER_BOUNDED);
+  const bool ext = ext_flags != 0;
+  if (ext && sc->no_alloc) {
+    g_last_error = "rtmi_render_device_noalloc: the shadow-ray extension flags are not supported";
+    return RTMI_ERR_UNSUPPORTED;
+  }
   const bool use_tree = p->search == RTMI_SEARCH_CONE_TREE;
   const bool nearest = p->hit_policy == RTMI_HIT_NEAREST;
   if (nearest && !use_tree) {
@@ -812,6 +898,13 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
     return RTMI_ERR_INVALID_ARGUMENT;
   }
   HIP_TRY(hipSetDevice(sc->device));
+  ExtArgs ext_args{};
+  if (ext_flags & RTMI_FLAG_SHADOWS_ENTER_BOUNDED) {
+    int32_t rc_b = ensure_bounded_tree(sc);
+    if (rc_b) return rc_b;
+    ext_args = sc->bounded_args;
+  }
+  ext_args.flags = ext_flags;
 
   // camera frame: RayTracingFunctions.swift:156-170, WorldCoordinateSequence.swift:58-59
   FrameConst fc{};
@@ -1094,11 +1187,13 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
           hipLaunchKernelGGL(k_search_finish, dim3(grid), dim3(256), 0, st, sc->d_sargs + gi, par);
         else {
           // pixels only, and a scene whose secondary rays cannot change one: the instantiation without them
-          const bool inert = sc->inert_secondary && (p->flags & RTMI_FLAG_NO_RAY_STATISTICS) != 0;
+          const bool inert = !ext && sc->inert_secondary && (p->flags & RTMI_FLAG_NO_RAY_STATISTICS) != 0;
 #define RTMI_LAUNCH_SHADE_CANDIDATES(kernel)                                                                              \
   hipLaunchKernelGGL(kernel, dim3(sc->exact_grid), dim3(256), 0, st, shc, sc->dev, sc->top_args, (const f2*)sc->d_trec, \
                      (const float*)sc->d_gst2, (const int*)sc->groups[0].d_slot_pos, sc->d_sargs + gi, sc->wb.rgb, par)
-          if (nearest) {
+          if (ext) {
+            RTMI_LAUNCH_SHADE_CANDIDATES((k_shade_candidates<false, false, false, true>));  // queue every intersection
+          } else if (nearest) {
             if (has_top_runs) RTMI_LAUNCH_SHADE_CANDIDATES((k_shade_candidates<true, false, true>));
             else if (inert) RTMI_LAUNCH_SHADE_CANDIDATES((k_shade_candidates<false, true, true>));
             else RTMI_LAUNCH_SHADE_CANDIDATES((k_shade_candidates<false, false, true>));
@@ -1128,7 +1223,7 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
     // the shade queue stays empty when the cone tree shades every triangle hit itself and the scene
     // lists nothing else that can be shaded (no sphere or light object, no top-level triangles) and
     // nothing with a material that a reflected ray could find (k_shade_candidates queues those samples)
-    if (!(use_tree && !has_top_runs && sc->n_plain_shadeable == 0 && !sc->lean_may_defer)) {
+    if (ext || !(use_tree && !has_top_runs && sc->n_plain_shadeable == 0 && !sc->lean_may_defer)) {
       if (b0 == 0) HIP_TRY(hipEventRecord(sc->ev_c, st));  // timed for the first batch only (frames are one batch as a rule)
 #define RTMI_LAUNCH_SHADE(kernel)                                                                                            \
   hipLaunchKernelGGL(kernel, dim3(std::min(grid, 4 * sc->exact_grid)), dim3(256), 0, st, shc, sc->dev, sc->top_args,         \
@@ -1146,7 +1241,16 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
                        sc->wb.dirs, sc->wb.tval, sc->wb.q_shade, &sc->wb.cnt->q_shade, sc->wb.hit_id, sc->wb.rgb,           \
                        sc->wb.cnt, (const int*)sc->wb.tri_hit, (const unsigned*)sc->wb.q_top);                              \
   } while (0)
-      if (has_top_runs && trace_then_shade() && sc->dev.n_lights <= TRACE_MAX_LIGHTS) {
+#define RTMI_LAUNCH_SHADE_EXT(NEAREST)                                                                                       \
+  hipLaunchKernelGGL((k_shade_ext<NEAREST>), dim3(std::min(grid, 4 * sc->exact_grid)), dim3(256), 0, st, shc, sc->dev,      \
+                     sc->top_args, (const f2*)sc->d_trec, (const float*)sc->d_gst2, (const int*)sc->groups[0].d_slot_pos,   \
+                     ext_args, (const f2*)sc->d_brec, (const float*)sc->d_bgst2, (const int*)sc->d_bslot_pos,               \
+                     (const int*)sc->d_bmembers, (const int*)sc->d_bowner, sc->wb.dirs, sc->wb.tval, sc->wb.q_shade,         \
+                     &sc->wb.cnt->q_shade, sc->wb.hit_id, sc->wb.rgb, sc->wb.cnt)
+      if (ext) {
+        if (nearest) RTMI_LAUNCH_SHADE_EXT(true);
+        else RTMI_LAUNCH_SHADE_EXT(false);
+      } else if (has_top_runs && trace_then_shade() && sc->dev.n_lights <= TRACE_MAX_LIGHTS) {
         if (nearest) RTMI_LAUNCH_TRACE_REPLAY(true);
         else RTMI_LAUNCH_TRACE_REPLAY(false);
       } else if (nearest) {
@@ -1156,6 +1260,7 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
         if (has_top_runs) RTMI_LAUNCH_SHADE((k_shade<true, false>));
         else RTMI_LAUNCH_SHADE((k_shade<false, false>));
       }
+#undef RTMI_LAUNCH_SHADE_EXT
 #undef RTMI_LAUNCH_TRACE_REPLAY
 #undef RTMI_LAUNCH_SHADE
       if (b0 == 0) HIP_TRY(hipEventRecord(sc->ev_d, st));

@@ -24,18 +24,18 @@ OUT = os.path.dirname(os.path.abspath(__file__))
 ONLY = sys.argv[1:]  # fixture names to (re)generate; none = all
 
 
-def save(name, data, cam_kw, W, H, sub, ambient=(0.2, 0.2, 0.2), hit_policy=0):
+def save(name, data, cam_kw, W, H, sub, ambient=(0.2, 0.2, 0.2), hit_policy=0, flags=0):
     if ONLY and name not in ONLY:
         return
     cam = scenes.make_camera(**cam_kw)
-    params = scenes.make_params(W, H, sub, ambient, hit_policy=hit_policy)
+    params = scenes.make_params(W, H, sub, ambient, hit_policy=hit_policy, flags=flags)
     rgba, hit, cnt = oracle.render(data, cam, params)
     arrs = data.to_arrays()
     np.savez_compressed(
         os.path.join(OUT, name + ".npz"),
         cam=np.array(list(cam_kw["pos"]) + list(cam_kw["direction"]) + [cam_kw["focal_length"]], np.float64),
         params=np.array([W, H, sub] + list(ambient), np.float64),
-        rgba=rgba, hit=hit, hit_policy=np.array([hit_policy], np.int64),
+        rgba=rgba, hit=hit, hit_policy=np.array([hit_policy], np.int64), flags=np.array([flags], np.int64),
         counters=np.array([cnt[k] for k in ("samples", "rays_reflection", "rays_shadow", "tri_tests",
                                             "sphere_tests", "primary_hits")], np.int64),
         **arrs)
@@ -97,6 +97,13 @@ def main():
          scenes.MESH_CAMERA, 48, 40, 0.5, hit_policy=1)
     save("mixed_nearest_3L_64x48", mixed_scene(), dict(pos=(0.5, 0.8, 5.0), direction=(-0.05, -0.12, -1.0), focal_length=8.0),
          64, 48, 0.5, ambient=(0.25, 0.2, 0.3), hit_policy=1)
+    # the shadow-ray extensions: RTMI_FLAG_SHADOWS_ENTER_BOUNDED (4) on a non-convex bounded mesh whose triangles carry
+    # a material (its folds then shadow one another), and both flags (6) on the mixed scene
+    folded = scenes.mesh_scene(2, "B", 3, bounding_sphere=oracle.bounding_sphere)
+    folded.triangles["material"] = 0
+    save("ico2_bounded_shadows_enter_48x40", folded, scenes.MESH_CAMERA, 48, 40, 0.5, flags=4)
+    save("mixed_shadow_extensions_3L_64x48", mixed_scene(), dict(pos=(0.5, 0.8, 5.0), direction=(-0.05, -0.12, -1.0), focal_length=8.0),
+         64, 48, 0.5, ambient=(0.25, 0.2, 0.3), flags=6)
 
 
 if __name__ == "__main__":

@@ -26,6 +26,7 @@ def load_golden(name):
     cam = scenes.make_camera(c[0:3], c[3:6], c[6])
     p = z["params"]
     policy = int(z["hit_policy"][0]) if "hit_policy" in z.files else 0  # 1: the nearest-hit extension
-    params = scenes.make_params(int(p[0]), int(p[1]), float(p[2]), tuple(p[3:6]), hit_policy=policy)
+    flags = int(z["flags"][0]) if "flags" in z.files else 0  # the shadow-ray extensions (RTMI_FLAG_SHADOW_*)
+    params = scenes.make_params(int(p[0]), int(p[1]), float(p[2]), tuple(p[3:6]), hit_policy=policy, flags=flags)
     counters = dict(zip(COUNTER_KEYS, (int(x) for x in z["counters"])))
     return data, cam, params, z["rgba"], z["hit"], counters

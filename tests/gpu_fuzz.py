@@ -92,6 +92,8 @@ def main(argv=None):
         nearest = i % 3 == 2
         if nearest:
             params.hit_policy = _abi.RTMI_HIT_NEAREST
+        if i % 4 == 1:  # every fourth case with the shadow-ray extensions: distance limit, entering bounding spheres, both
+            params.flags = [2, 4, 6][(i // 4) % 3]
         if a.extras and i % 4 == 3:  # many lights (more than 16: the shading kernel that traces its own rays)
             rng = np.random.default_rng([a.seed, i, 99])
             n = int(rng.choice([5, 9, 16, 17, 20]))
@@ -109,7 +111,7 @@ def main(argv=None):
                 p2 = copy.copy(params)
                 o2_rgba, o2_hit, _ = oracle.render(data, cam2, p2, threads=a.threads)
                 p3 = copy.copy(params)
-                p3.flags = _abi.RTMI_FLAG_NO_RAY_STATISTICS
+                p3.flags |= _abi.RTMI_FLAG_NO_RAY_STATISTICS
                 try:
                     g2_rgba, g2_hit, _ = sc.render(cam2, p2)
                     g3_rgba, g3_hit, _ = sc.render(cam, p3)

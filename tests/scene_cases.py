@@ -50,3 +50,27 @@ def toplevel_mesh_with_company(n_lights, level=2):
         scenes.light_object(0),
     ])
     return scenes.SceneData(lights=lights, materials=mats, objects=objects, triangles=tris)
+
+
+def shadow_extension_cases(bounding_sphere):
+    """Scenes on which the two shadow-ray extensions change pixels: a non-convex bounded mesh with a material (its
+    folds shadow one another once shadow rays enter the bounding sphere), lights between objects (a sphere or a
+    top-level triangle behind a light stops shadowing with the distance limit), a light listed as an object."""
+    bounded = scenes.mesh_scene(1, "B", 3, bounding_sphere=bounding_sphere, shuffle_seed=4)
+    bounded.triangles["material"] = 0
+    company = scenes.mesh_scene(1, "B", 2, bounding_sphere=bounding_sphere)
+    company.triangles["material"] = 0
+    # a light between the mesh and a sphere, and the same light listed as an object; top-level triangles behind another
+    lights = np.concatenate([scenes.light(loc=(2.2, 0.3, 0.4), specular=(0.8, 0.8, 0.8), diffuse=(0.5, 0.5, 0.5)),
+                             scenes.light(loc=(-0.2, 2.0, 0.6), specular=(0.6, 0.7, 0.8), diffuse=(0.5, 0.4, 0.3))])
+    wall = np.zeros(2, scenes.TRI_DTYPE)
+    wall["v"][0] = [(-2.5, 3.5, -2.0), (2.5, 3.5, 2.0), (2.5, 3.5, -2.0)]
+    wall["v"][1] = [(-2.5, 3.5, -2.0), (-2.5, 3.5, 2.0), (2.5, 3.5, 2.0)]
+    wall["material"] = 0
+    n = len(company.triangles)
+    company = scenes.SceneData(lights=lights, materials=company.materials,
+                               triangles=np.concatenate([company.triangles, wall]),
+                               objects=np.concatenate([company.objects, scenes.sphere_object((3.6, 0.5, 0.6), 0.8, 0),
+                                                       scenes.light_object(0), scenes.triangles_object(n, 2)]))
+    return [(bounded, scenes.make_camera(**scenes.MESH_CAMERA)),
+            (company, scenes.make_camera((0.8, 0.9, 5.0), (-0.05, -0.12, -1.0), 7.0))]

@@ -12,14 +12,14 @@ import pytest
 
 import emu_util
 from golden_util import golden_names, load_golden
-from scene_cases import light_hit_scene, toplevel_mesh_with_company
+from scene_cases import light_hit_scene, shadow_extension_cases, toplevel_mesh_with_company
 from raytracer_amd import _abi, scenes, sharding
 
 SEARCHES = {"tree": _abi.RTMI_SEARCH_CONE_TREE, "scan": _abi.RTMI_SEARCH_LIST_SCAN}
 PARITY_COUNTERS = ("samples", "rays_reflection", "rays_shadow", "sphere_tests", "primary_hits")
 # kernels whose wave-level votes are meant to be reached by part of a wave (the secondary-ray tree walk is
 # called from divergent shading code); everywhere else a vote that misses live lanes is a defect
-DIVERGENT_OK = ("k_shade<true, ", "k_shade_candidates<true, ", "k_trace_top<", "k_shade_replay<")
+DIVERGENT_OK = ("k_shade<true, ", "k_shade_candidates<true, ", "k_trace_top<", "k_shade_replay<", "k_shade_ext<")
 
 
 @pytest.fixture(scope="module")
@@ -311,6 +311,21 @@ def test_emulated_lean_shading_hands_over_to_the_full_kernel(emu, oracle_mod, tm
     data = scenes.mesh_scene(1, "B", 2, bounding_sphere=oracle_mod.bounding_sphere)
     data.objects = np.concatenate([data.objects, scenes.sphere_object((1.9, 0.3, 0.4), 0.7, 0)])
     run_case(emu, oracle_mod, tmp_path / "sphere", data, [cam], scenes.make_params(48, 32, 0.5), searches=("tree",))
+
+
+@pytest.mark.parametrize("flags", [_abi.RTMI_FLAG_SHADOW_MAX_DISTANCE, _abi.RTMI_FLAG_SHADOWS_ENTER_BOUNDED,
+                                   _abi.RTMI_FLAG_SHADOW_MAX_DISTANCE | _abi.RTMI_FLAG_SHADOWS_ENTER_BOUNDED])
+def test_emulated_shadow_extensions(emu, oracle_mod, tmp_path, flags):
+    """The two extensions of the shadow test (a distance limit; shadow rays that enter bounding spheres): every hit goes
+    through the shade queue to k_shade_ext, which walks the top-level runs' tree and the tree over the bounded
+    children.  Both searches, both hit policies (the nearest-hit policy with the cone tree only), two frames on one
+    scene object (the bounded tree is built by the first)."""
+    for k, (data, cam) in enumerate(shadow_extension_cases(oracle_mod.bounding_sphere)):
+        out = run_case(emu, oracle_mod, tmp_path / f"lo{k}", data, [cam, cam], scenes.make_params(40, 32, 0.5, flags=flags))
+        plain = oracle_mod.render(data, cam, scenes.make_params(40, 32, 0.5), threads=4)[0]
+        assert (out["tree"][0][0] != plain).any()  # the flags do change this frame
+        run_case(emu, oracle_mod, tmp_path / f"nr{k}", data, [cam],
+                 scenes.make_params(40, 32, 0.5, flags=flags, hit_policy=_abi.RTMI_HIT_NEAREST), searches=("tree",))
 
 
 def test_emulated_pixels_only_flag_gives_the_same_frame(emu, oracle_mod, tmp_path):

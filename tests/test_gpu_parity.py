@@ -570,7 +570,7 @@ def test_pixels_only_flag_gives_the_same_frame_without_secondary_rays(oracle_mod
                 assert g_cnt["rays_reflection"] == 0 and g_cnt["rays_shadow"] == 0
         sc.close()
     with pytest.raises(rt.RtmiError):
-        rt.Scene(scenes.two_sphere_scene()).render(scenes.make_camera(**scenes.VC_CAMERA), scenes.make_params(32, 32, flags=6))
+        rt.Scene(scenes.two_sphere_scene()).render(scenes.make_camera(**scenes.VC_CAMERA), scenes.make_params(32, 32, flags=24))
 
 
 def test_nearest_hit_extension(oracle_mod, rt):
@@ -605,6 +605,43 @@ def test_nearest_hit_extension(oracle_mod, rt):
             sc.render(c_, scenes.make_params(W, H, sub, hit_policy=_abi.RTMI_HIT_NEAREST, search=_abi.RTMI_SEARCH_LIST_SCAN))
         sc.close()
     assert differs > 1000
+
+
+@pytest.mark.parametrize("flags", [_abi.RTMI_FLAG_SHADOW_MAX_DISTANCE, _abi.RTMI_FLAG_SHADOWS_ENTER_BOUNDED,
+                                   _abi.RTMI_FLAG_SHADOW_MAX_DISTANCE | _abi.RTMI_FLAG_SHADOWS_ENTER_BOUNDED])
+def test_shadow_ray_extensions(oracle_mod, rt, flags):
+    """RTMI_FLAG_SHADOW_MAX_DISTANCE and RTMI_FLAG_SHADOWS_ENTER_BOUNDED (extensions, not the reference's behaviour):
+    bit-exact against the oracle's implementation of the same rules, both searches and both hit policies, on a
+    folded bounded mesh with a material (1,280 triangles; its folds shadow one another once shadow rays enter the
+    bounding sphere), on a mesh in company of a sphere, a light listed as an object and top-level triangles behind a
+    light, and on a top-level mesh.  Each flag must change pixels."""
+    from scene_cases import shadow_extension_cases, toplevel_mesh_with_company
+    folded = scenes.mesh_scene(3, "B", 3, bounding_sphere=rt.bounding_sphere)
+    folded.triangles["material"] = 0
+    cases = [(folded, scenes.make_camera(**scenes.MESH_CAMERA), (240, 200, 0.5))]
+    cases += [(d, c, (160, 120, 0.5)) for d, c in shadow_extension_cases(rt.bounding_sphere)]
+    cases += [(toplevel_mesh_with_company(3, level=3), scenes.make_camera((0.9, 0.5, 4.0), (-0.12, -0.1, -1.0), 8.0), (160, 120, 0.5))]
+    changed = 0
+    for data, cam, (W, H, sub) in cases:
+        sc = rt.Scene(data)
+        plain = sc.render(cam, scenes.make_params(W, H, sub))[0]
+        for policy, search in ((0, _abi.RTMI_SEARCH_CONE_TREE), (0, _abi.RTMI_SEARCH_LIST_SCAN), (1, _abi.RTMI_SEARCH_CONE_TREE)):
+            p = scenes.make_params(W, H, sub, hit_policy=policy, search=search, flags=flags)
+            o_rgba, o_hit, o_cnt = oracle_mod.render(data, cam, p, threads=16)
+            for rep in range(2):
+                g_rgba, g_hit, g_cnt = sc.render(cam, p)
+                assert (g_hit == o_hit).all(), f"{int((g_hit != o_hit).sum())} hit-id mismatches of {o_hit.size}"
+                assert (g_rgba == o_rgba).all(), f"{int((g_rgba != o_rgba).any(axis=-1).sum())} pixels differ"
+                for k in ("samples", "rays_reflection", "rays_shadow", "primary_hits"):
+                    assert g_cnt[k] == o_cnt[k], k
+            if policy == 0:
+                changed += int((o_rgba != plain).any(axis=-1).sum())
+        # the flags leave no trace on the scene object: the reference's frame comes out as before
+        assert (sc.render(cam, scenes.make_params(W, H, sub))[0] == plain).all()
+        with pytest.raises(rt.RtmiError):  # an unknown flag bit
+            sc.render(cam, scenes.make_params(16, 16, 1.0, flags=flags | 64))
+        sc.close()
+    assert changed > 500
 
 
 @pytest.mark.parametrize("n_lights", [3, 16, 17])

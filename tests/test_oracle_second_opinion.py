@@ -9,7 +9,7 @@ import pytest
 from golden_util import load_golden
 from oracle import swift_walkthrough as sw
 from raytracer_amd import scenes
-from scene_cases import light_hit_scene
+from scene_cases import light_hit_scene, shadow_extension_cases
 
 
 def agree(oracle_mod, data, cam, params):
@@ -113,3 +113,18 @@ def test_second_restatement_agrees_on_the_nearest_hit_extension(oracle_mod):
         b = oracle_mod.render(d, c, scenes.make_params(size[0], size[1], size[2]))[1]
         differs += int((a != b).sum())
     assert differs > 0  # the extension does change hits on these scenes
+
+
+@pytest.mark.parametrize("flags", [2, 4, 6])
+def test_second_restatement_agrees_on_the_shadow_extensions(oracle_mod, flags):
+    """RTMI_FLAG_SHADOW_MAX_DISTANCE (2) and RTMI_FLAG_SHADOWS_ENTER_BOUNDED (4) in the C oracle against their
+    statement in the Python restatement (shadow_blockers), with both hit policies; each flag must change pixels."""
+    changed = 0
+    for data, cam in shadow_extension_cases(oracle_mod.bounding_sphere):
+        for policy in (0, 1):
+            p = scenes.make_params(16, 14, 0.5, hit_policy=policy, flags=flags)
+            agree(oracle_mod, data, cam, p)
+            a = oracle_mod.render(data, cam, p)[0]
+            b = oracle_mod.render(data, cam, scenes.make_params(16, 14, 0.5, hit_policy=policy))[0]
+            changed += int((a != b).any(axis=-1).sum())
+    assert changed > 0

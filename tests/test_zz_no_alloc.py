@@ -73,6 +73,12 @@ def test_noalloc_matches_render_device_on_consecutive_calls(rt):
         with pytest.raises(rt.RtmiError) as e:
             sc.render_device_noalloc(cam, wide, rgba.data_ptr())
         assert e.value.status == _abi.RTMI_ERR_UNSUPPORTED
+        # the shadow-ray extensions build a tree of their own on first use: refused here
+        small = torch.zeros((16, 16, 4), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        with pytest.raises(rt.RtmiError) as e:
+            sc.render_device_noalloc(cam, scenes.make_params(16, 16, 1.0, flags=_abi.RTMI_FLAG_SHADOWS_ENTER_BOUNDED), small.data_ptr())
+        assert e.value.status == _abi.RTMI_ERR_UNSUPPORTED
         sc.render_device(cam, big, torch.zeros((300, 400, 4), dtype=torch.uint8, device="cuda").data_ptr())
         sc.close()
         ref_sc.close()
