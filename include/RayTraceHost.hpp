@@ -115,12 +115,20 @@ struct Sphere {
 // a PointLight is a class in the reference; objects hold a reference to one of `lights`
 using WorldObject = std::variant<Sphere, Triangle, std::shared_ptr<PointLight>>;
 
+// What the library offers beyond the reference's behaviour; everything off = the reference.
+struct RenderExtensions {
+  bool nearestHit = false;            // RTMI_HIT_NEAREST: intersections.min(by: parameter) instead of intersections[0]
+  bool shadowMaxDistance = false;     // RTMI_FLAG_SHADOW_MAX_DISTANCE: only what lies before the light casts a shadow
+  bool shadowsEnterBounded = false;   // RTMI_FLAG_SHADOWS_ENTER_BOUNDED: the TODO at RayTracingFunctions.swift:240
+};
+
 inline void raytraceWorld(v3d camera, v3d cameraDirection, double focalLength, int /*imageWidthPixels*/,
                           int /*imageHeightPixels*/,  // both ignored: the reference uses the globals (:170)
                           RGB ambientLight, const std::vector<std::shared_ptr<PointLight>>& lights,
                           const std::vector<WorldObject>& objects, const std::map<std::string, Material>& /*materialDictionary*/,
                           std::vector<uint8_t>& outputBitmap, const std::function<void()>& pixelDone = nullptr,
-                          double pixelSubdivision = 1.0 /* :170 hard-codes 1 */, int device = 0) {
+                          double pixelSubdivision = 1.0 /* :170 hard-codes 1 */, int device = 0,
+                          RenderExtensions extensions = {}) {
   if (outputBitmap.size() != (size_t)4 * imageWidth * imageHeight)
     throw std::out_of_range("outputBitmap must hold 4 * imageWidth * imageHeight bytes");  // Swift traps on the index
   std::vector<rtmi_light> cl;
@@ -195,7 +203,9 @@ inline void raytraceWorld(v3d camera, v3d cameraDirection, double focalLength, i
   p.width = imageWidth; p.height = imageHeight;
   p.pixel_subdivision = pixelSubdivision;
   p.ambient[0] = ambientLight.red; p.ambient[1] = ambientLight.green; p.ambient[2] = ambientLight.blue;
-  p.hit_policy = RTMI_HIT_LIST_ORDER;
+  p.hit_policy = extensions.nearestHit ? RTMI_HIT_NEAREST : RTMI_HIT_LIST_ORDER;
+  p.flags = (extensions.shadowMaxDistance ? RTMI_FLAG_SHADOW_MAX_DISTANCE : 0) |
+            (extensions.shadowsEnterBounded ? RTMI_FLAG_SHADOWS_ENTER_BOUNDED : 0);
   rtmi_counters counters{};
   rc = rtmi_render(scene, &cam, &p, outputBitmap.data(), nullptr, &counters);
   rtmi_scene_destroy(scene);

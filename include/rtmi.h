@@ -160,10 +160,10 @@ typedef struct {
  *                                  children as well, and a child that is hit blocks the light: the reference's own
  *                                  "TODO seems like I'm forgetting to intersect with shapes inside the bounding
  *                                  shape" (:240).  Reflection rays are unchanged.
- * With either flag the hits of a frame are shaded by one general kernel after the search (no rays are left out:
- * RTMI_FLAG_NO_RAY_STATISTICS has no effect), and rtmi_render_device_noalloc refuses the frame
- * (RTMI_ERR_UNSUPPORTED).  RTMI_FLAG_SHADOWS_ENTER_BOUNDED needs every triangle to be listed by at most one
- * object (else RTMI_ERR_UNSUPPORTED). */
+ * With either flag every hit of a frame is shaded from a queue after the search, all its secondary rays traced
+ * (RTMI_FLAG_NO_RAY_STATISTICS has no effect), and rtmi_render_device_noalloc refuses the frame
+ * (RTMI_ERR_UNSUPPORTED): the first frame that asks for RTMI_FLAG_SHADOWS_ENTER_BOUNDED builds a bounding-sphere
+ * tree over the children of all bounding spheres and keeps it with the scene. */
 #define RTMI_FLAG_SHADOW_MAX_DISTANCE 2
 #define RTMI_FLAG_SHADOWS_ENTER_BOUNDED 4
 

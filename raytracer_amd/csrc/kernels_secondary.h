@@ -571,9 +571,24 @@ struct ExtRef {
   double c0[3];
 };
 
+__device__ inline ExtRef make_ext_ref(const ExtArgs& ea, const f2* brec, const float* bgst2, const int* bslot_pos,
+                                      const int* bmembers, const int* bowner) {
+  ExtRef ext;
+  ext.flags = ea.flags;
+  ext.bounded = make_top_tree(ea.tree, brec, bgst2, bslot_pos);
+  ext.members = bmembers;
+  ext.member_owner = bowner;
+  ext.n_bounded = ea.n_bounded;
+  ext.c0[0] = ea.c0[0]; ext.c0[1] = ea.c0[1]; ext.c0[2] = ea.c0[2];
+  return ext;
+}
+
 // The shadow test RTF:236-243 with the extensions: does anything other than a bounding sphere intersect the
 // ray at a parameter below max_t (INFINITY without RTMI_FLAG_SHADOW_MAX_DISTANCE), counting -- with
 // RTMI_FLAG_SHADOWS_ENTER_BOUNDED -- the children of every bounding sphere the ray intersects.
+// WALK_TOP / WALK_BOUNDED false: the caller knows that the scene has no top-level runs / that the frame does not
+// enter bounding spheres, and the walk is left out of the code.
+template <bool WALK_TOP = true, bool WALK_BOUNDED = true>
 __device__ inline bool shadow_blocked_ext(const SceneDev& sc, const TopTreeRef& tt, const ExtRef& ext, d3 o, d3 d, double max_t,
                                           tally_t* n_tests) {
 #pragma nounroll
@@ -590,14 +605,14 @@ __device__ inline bool shadow_blocked_ext(const SceneDev& sc, const TopTreeRef& 
   }
   double t;
   d3 P;
-  if (sc.n_top_tris > 0) {
+  if (WALK_TOP && sc.n_top_tris > 0) {
     WalkExt w;
     w.members = sc.top_group; w.member_owner = nullptr; w.n_members = sc.n_top_tris;
     w.c0[0] = sc.c0[0]; w.c0[1] = sc.c0[1]; w.c0[2] = sc.c0[2];
     w.max_t = max_t;
     if (top_tree_trace<true>(sc, tt, o, d, true, &t, &P, n_tests, &w) >= 0) return true;
   }
-  if ((ext.flags & RTMI_FLAG_SHADOWS_ENTER_BOUNDED) && ext.n_bounded > 0) {
+  if (WALK_BOUNDED && (ext.flags & RTMI_FLAG_SHADOWS_ENTER_BOUNDED) && ext.n_bounded > 0) {
     WalkExt w;
     w.members = ext.members; w.member_owner = ext.member_owner; w.n_members = ext.n_bounded;
     w.c0[0] = ext.c0[0]; w.c0[1] = ext.c0[1]; w.c0[2] = ext.c0[2];

@@ -16,6 +16,10 @@ constexpr int SHADE_INERT_WAVES = RTMI_SHADE_INERT_WAVES;
 #define RTMI_TRACE_TOP_WAVES 4
 #endif
 constexpr int TRACE_TOP_WAVES = RTMI_TRACE_TOP_WAVES;  // resident waves per SIMD k_trace_top is compiled for
+#ifndef RTMI_TRACE_EXT_WAVES
+#define RTMI_TRACE_EXT_WAVES 4
+#endif
+constexpr int TRACE_EXT_WAVES = RTMI_TRACE_EXT_WAVES;  // the same for its instantiation with the shadow-ray extensions
 
 struct RGBd {
   double r, g, b;
@@ -158,14 +162,16 @@ __device__ __forceinline__ bool traced_any(const SceneDev& sc, const TopTreeRef&
 // changes a pixel -- a bounding sphere blocks no light (RTF:241) and, lacking a material, reflects none
 // (RTF:192, :245) -- so the rays are neither traced nor counted (the caller asked for pixels, not for the
 // reference's ray statistics: RTMI_FLAG_NO_RAY_STATISTICS).
-// EXT (with neither LEAN nor INERT, MODE TRACE_LIVE): the shadow test of the light loop follows *ext
+// EXT (with neither LEAN nor INERT; tracing or recording, a replay does not care how the outcomes came about): the
+// shadow test of the light loop follows *ext
 // (RTMI_FLAG_SHADOW_MAX_DISTANCE, RTMI_FLAG_SHADOWS_ENTER_BOUNDED; shadow_blocked_ext) instead of RTF:236-243.
+// EXT_ENTER false: the frame does not ask for RTMI_FLAG_SHADOWS_ENTER_BOUNDED (the walk of the bounded tree is left out).
 template <bool REFLECT, bool HAS_TOP, bool LEAN = false, bool INERT = false, bool NEAREST = false, int MODE = TRACE_LIVE,
-          bool EXT = false>
+          bool EXT = false, bool EXT_ENTER = true>
 __device__ __forceinline__ RGBd calculate_lighting(const SceneDev& sc, const TopTreeRef& tt, const ShadeConst& fc, const Hit& is, d3 camera,
                                    tally_t* n_refl, tally_t* n_shadow, tally_t* n_tests, tally_t* n_elided, bool* defer = nullptr,
                                    TraceRec* rec = nullptr, const ExtRef* ext = nullptr) {
-  static_assert(!EXT || (!LEAN && !INERT && MODE == TRACE_LIVE), "the extensions run in the general instantiation only");
+  static_assert(!EXT || (!LEAN && !INERT && MODE != TRACE_REPLAY), "the extensions trace in the general instantiation only");
   d3 surface_point = is.P;
   RGBd I = {0.0, 0.0, 0.0};
   const bool has_material = is.material >= 0;
@@ -223,8 +229,8 @@ __device__ __forceinline__ RGBd calculate_lighting(const SceneDev& sc, const Top
     } else {
       *n_refl += 1;
       if (traced_first<MODE, HAS_TOP, NEAREST>(sc, tt, surface_point, reflection, &rh, n_tests, rec)) {
-        contribution = calculate_lighting<false, HAS_TOP, false, false, NEAREST, MODE, EXT>(sc, tt, fc, rh, surface_point, n_refl,
-                                                                                            n_shadow, n_tests, n_elided, nullptr, rec, ext);
+        contribution = calculate_lighting<false, HAS_TOP, false, false, NEAREST, MODE, EXT, EXT_ENTER>(
+            sc, tt, fc, rh, surface_point, n_refl, n_shadow, n_tests, n_elided, nullptr, rec, ext);
       }
     }
     I.r = I.r + contribution.r;
@@ -254,7 +260,9 @@ __device__ __forceinline__ RGBd calculate_lighting(const SceneDev& sc, const Top
       const double max_t = (ext->flags & RTMI_FLAG_SHADOW_MAX_DISTANCE)
                                ? sqrt(rtx::len_squared(rtx::sub(rtx::ld3(light.loc), surface_point)))
                                : INFINITY;
-      if (shadow_blocked_ext(sc, tt, *ext, surface_point, point_to_light, max_t, n_tests)) return;
+      const bool blocked = shadow_blocked_ext<HAS_TOP, EXT_ENTER>(sc, tt, *ext, surface_point, point_to_light, max_t, n_tests);
+      if constexpr (MODE == TRACE_RECORD) rec->bits |= (blocked ? 1u : 0u) << shadow_key(li, REFLECT ? 0 : 1);
+      if (blocked) return;
     } else if constexpr (!INERT) {
       *n_shadow += 1;
       if (traced_any<MODE, HAS_TOP, NEAREST>(sc, tt, surface_point, point_to_light, n_tests, rec, shadow_key(li, REFLECT ? 0 : 1)))
@@ -362,7 +370,7 @@ __device__ __forceinline__ bool primary_hit(const SceneDev& sc, d3 cam, d3 d, in
 // t_tri is the triangle's intersection parameter.  LEAN: returns true, with nothing counted or stored,
 // if the sample needs the full instantiation (see calculate_lighting).
 // MODE (see TraceRec): TRACE_RECORD traces the sample's secondary rays into *rec and stores no colour.
-template <bool HAS_TOP, bool LEAN = false, bool NEAREST = false, int MODE = TRACE_LIVE, bool EXT = false>
+template <bool HAS_TOP, bool LEAN = false, bool NEAREST = false, int MODE = TRACE_LIVE, bool EXT = false, bool EXT_ENTER = true>
 __device__ __forceinline__ bool shade_sample(const ShadeConst& fc, const SceneDev& sc, const TopTreeRef& tt, int s, d3 d,
                                              int id, double t_tri, double* rgb, ShadeTally* tl, TraceRec* rec = nullptr,
                                              const ExtRef* ext = nullptr) {
@@ -373,8 +381,8 @@ __device__ __forceinline__ bool shade_sample(const ShadeConst& fc, const SceneDe
   if (ok) {
     bool defer = false;
     static_assert(!LEAN, "the lean lighting needs a wave-uniform material: shade_triangle_lean");
-    c = calculate_lighting<true, HAS_TOP, false, false, NEAREST, MODE, EXT>(sc, tt, fc, h, cam, &tl->n_refl, &tl->n_shadow, &tl->n_tests,
-                                                                            &tl->n_elided, &defer, rec, ext);
+    c = calculate_lighting<true, HAS_TOP, false, false, NEAREST, MODE, EXT, EXT_ENTER>(sc, tt, fc, h, cam, &tl->n_refl, &tl->n_shadow,
+                                                                                       &tl->n_tests, &tl->n_elided, &defer, rec, ext);
     tl->n_hit += 1;
   }
   if constexpr (MODE != TRACE_RECORD) {
@@ -435,7 +443,7 @@ k_shade(ShadeConst fc, SceneDev sc, TopTreeArgs ta, const f2* __restrict__ trec,
 }
 
 // k_shade with the shadow-ray extensions: every hit of the frame comes through the shade queue (see
-// k_shade_candidates, QUEUE_ALL) and is shaded here by the general instantiation.  The top-level runs' tree is
+// k_queue_candidates) and is shaded here by the general instantiation.  The top-level runs' tree is
 // walked if the scene has one (its root count is zero otherwise); b* are the bounded tree's arrays.
 template <bool NEAREST>
 __global__ void __launch_bounds__(256)
@@ -445,13 +453,7 @@ k_shade_ext(ShadeConst fc, SceneDev sc, TopTreeArgs ta, const f2* __restrict__ t
             const double* __restrict__ dirs, const double* __restrict__ tval, const int* __restrict__ q_shade,
             const int* __restrict__ nq_ptr, const int* __restrict__ hit_id, double* rgb, DevCounters* cnt) {
   const TopTreeRef tt = make_top_tree(ta, trec, gst2, tslot_pos);
-  ExtRef ext;
-  ext.flags = ea.flags;
-  ext.bounded = make_top_tree(ea.tree, brec, bgst2, bslot_pos);
-  ext.members = bmembers;
-  ext.member_owner = bowner;
-  ext.n_bounded = ea.n_bounded;
-  ext.c0[0] = ea.c0[0]; ext.c0[1] = ea.c0[1]; ext.c0[2] = ea.c0[2];
+  const ExtRef ext = make_ext_ref(ea, brec, bgst2, bslot_pos, bmembers, bowner);
   ShadeTally tl;
   const int nq = *nq_ptr;
   for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
@@ -473,13 +475,20 @@ k_shade_ext(ShadeConst fc, SceneDev sc, TopTreeArgs ta, const f2* __restrict__ t
 // the latency of the walks.  k_shade_replay then evaluates the lighting from the recorded outcomes without
 // tracing anything.  The sphere tests are counted where the rays are traced, hits and rays by k_shade_replay.
 // k_trace_top runs the lighting code itself in recording mode.
-template <bool NEAREST>
-__global__ void __launch_bounds__(256, TRACE_TOP_WAVES)
+// EXT: the shadow rays follow the extension flags of `ea` (shadow_blocked_ext; b* are the bounded tree's arrays);
+// the replay is the same.  With EXT the kernel also serves scenes without top-level runs (HAS_TOP false) and frames
+// that do not enter bounding spheres (EXT_ENTER false): the walks that cannot happen are left out of the code.
+template <bool NEAREST, bool EXT = false, bool HAS_TOP = true, bool EXT_ENTER = true>
+__global__ void __launch_bounds__(256, EXT ? TRACE_EXT_WAVES : TRACE_TOP_WAVES)
 k_trace_top(ShadeConst fc, SceneDev sc, TopTreeArgs ta, const f2* __restrict__ trec, const float* __restrict__ gst2,
             const int* __restrict__ tslot_pos, const double* __restrict__ dirs, const double* __restrict__ tval,
             const int* __restrict__ q_shade, const int* __restrict__ nq_ptr, const int* __restrict__ hit_id, double* rgb,
-            DevCounters* cnt, int* rec_id, unsigned* rec_bits) {
+            DevCounters* cnt, int* rec_id, unsigned* rec_bits, ExtArgs ea, const f2* __restrict__ brec,
+            const float* __restrict__ bgst2, const int* __restrict__ bslot_pos, const int* __restrict__ bmembers,
+            const int* __restrict__ bowner) {
   const TopTreeRef tt = make_top_tree(ta, trec, gst2, tslot_pos);
+  ExtRef ext;
+  if constexpr (EXT) ext = make_ext_ref(ea, brec, bgst2, bslot_pos, bmembers, bowner);
   ShadeTally tl;
   const int nq = *nq_ptr;
   for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
@@ -490,7 +499,8 @@ k_trace_top(ShadeConst fc, SceneDev sc, TopTreeArgs ta, const f2* __restrict__ t
     else id = -2 - checked(-2 - id, sc.n_objects, cnt, 26);
     TraceRec rec;
     rec.id = -1; rec.t = 0.0; rec.bits = 0u;
-    shade_sample<true, false, NEAREST, TRACE_RECORD>(fc, sc, tt, s, d, id, id >= 0 ? tval[s] : 0.0, rgb, &tl, &rec);
+    shade_sample<HAS_TOP, false, NEAREST, TRACE_RECORD, EXT, EXT_ENTER>(fc, sc, tt, s, d, id, id >= 0 ? tval[s] : 0.0, rgb, &tl,
+                                                                        &rec, EXT ? &ext : nullptr);
     rec_id[q] = rec.id;
     rec_bits[q] = rec.bits;
     rgb[(size_t)s * 3 + 1] = rec.t;
@@ -534,8 +544,7 @@ k_shade_replay(ShadeConst fc, SceneDev sc, TopTreeArgs ta, const f2* __restrict_
 // Without top-level triangle runs the lean instantiation of the lighting runs here; the rare sample whose
 // reflected ray finds an object with a material goes to the shade queue (with its t), which k_shade serves
 // afterwards with the full instantiation.
-// QUEUE_ALL (with neither HAS_TOP nor INERT): nothing is shaded here; every intersection goes to the shade queue.
-template <bool HAS_TOP, bool INERT = false, bool NEAREST = false, bool QUEUE_ALL = false>
+template <bool HAS_TOP, bool INERT = false, bool NEAREST = false>
 __global__ void __launch_bounds__(256, HAS_TOP ? (NEAREST ? 1 : 2) : (INERT ? SHADE_INERT_WAVES : SHADE_LEAN_WAVES))
 k_shade_candidates(ShadeConst fc, SceneDev sc, TopTreeArgs ta, const f2* __restrict__ trec, const float* __restrict__ gst2,
                    const int* __restrict__ tslot_pos, const SearchArgs* __restrict__ ap, double* rgb, int par) {
@@ -583,10 +592,7 @@ k_shade_candidates(ShadeConst fc, SceneDev sc, TopTreeArgs ta, const f2* __restr
         tv = rtx::tri_t(sc.planes[ti], rtx::ld3(fc.cam), d);  // k_search_exact accepted this pair
         hit_id[s] = ti;
       }
-      if constexpr (QUEUE_ALL) {
-        static_assert(!QUEUE_ALL || (!HAS_TOP && !INERT), "QUEUE_ALL queues through the HAS_TOP == false path");
-        deferred = want;
-      } else if constexpr (HAS_TOP) {
+      if constexpr (HAS_TOP) {
         if (want) shade_sample<true, false, NEAREST>(fc, sc, tt, s, d, ti, tv, rgb, &tl);
       } else {
         if (want) deferred = shade_triangle_lean<INERT, NEAREST>(fc, sc, tt, s, d, ti, tv, rgb, &tl);
@@ -615,6 +621,63 @@ k_shade_candidates(ShadeConst fc, SceneDev sc, TopTreeArgs ta, const f2* __restr
   }
   search_lists_retire(cnt, par);
   shade_tally_flush(cnt, tl);
+}
+
+// The cone tree's last stage when the frame's hits are shaded from the shade queue (the shadow-ray extensions): the
+// candidate that is its ray's intersection gets its triangle index into hit_id and its parameter into tval, as
+// k_shade_candidates does it, and the sample is queued.  Nearly every candidate is one, so the appends are staged
+// per workgroup in LDS and handed over with one returning atomic per QUEUE_STAGE - 256 entries or more (a returning
+// atomic per wave and step on the one counter would take longer than the shading).
+constexpr int QUEUE_STAGE = 4096;
+__global__ void __launch_bounds__(256)
+k_queue_candidates(ShadeConst fc, SceneDev sc, const SearchArgs* __restrict__ ap, int par) {
+  __shared__ int stage[QUEUE_STAGE];
+  __shared__ int stage_n, stage_base;
+  DevCounters* cnt = ap->cnt;
+  int* q_shade = ap->q_shade;
+  if (threadIdx.x == 0) stage_n = 0;
+  __syncthreads();
+  auto flush = [&]() {  // reached by every thread of the workgroup
+    const int m = stage_n;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      stage_base = m ? atomicAdd(&cnt->q_shade, m) : 0;
+      stage_n = 0;
+    }
+    __syncthreads();
+    // every sample is queued at most once per frame, so the queue (one entry per sample) cannot overflow
+    for (int k = threadIdx.x; k < m; k += blockDim.x) q_shade[stage_base + k] = stage[k];
+    __syncthreads();
+  };
+  if (!cnt->overflow) {
+    const int list = blockIdx.x & (NSLOT - 1), part = blockIdx.x / NSLOT, parts = gridDim.x / NSLOT;
+    const int list_cap = ap->cand_cap / NSLOT;
+    const int n = min(cnt->cand_n[par][list][0], list_cap);
+    const int2* cand = ap->cand + (size_t)list * list_cap;
+    const int stride = parts * blockDim.x;
+    for (int base = part * blockDim.x; base < n; base += stride) {  // the same number of steps for the whole workgroup
+      const int i = base + threadIdx.x;
+      if (i < n) {
+        int2 c = cand[i];
+        c.x = checked(c.x, ap->n_samples, cnt, 35);
+        c.y = checked(c.y, ap->n_group, cnt, 36);
+        if (ap->best_pos[c.x] == c.y) {  // else another triangle of this ray is listed earlier, or the pair was no hit
+          const int s = c.x;
+          const int ti = checked(ap->group[c.y], ap->n_tris, cnt, 37);
+          const d3 d = rtx::mk(ap->dirs[(size_t)s * 3 + 0], ap->dirs[(size_t)s * 3 + 1], ap->dirs[(size_t)s * 3 + 2]);
+          ap->hit_id[s] = ti;
+          ap->tval[s] = rtx::tri_t(sc.planes[ti], rtx::ld3(fc.cam), d);  // k_search_exact accepted this pair
+          stage[atomicAdd(&stage_n, 1)] = s;
+        }
+      }
+      __syncthreads();
+      const int fill = stage_n;  // read by everyone before anyone appends again: the workgroup decides as one
+      __syncthreads();
+      if (fill > QUEUE_STAGE - 256) flush();
+    }
+  }
+  flush();
+  search_lists_retire(cnt, par);
 }
 
 // ---------------------------------------------------------------------------------------

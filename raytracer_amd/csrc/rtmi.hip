@@ -1191,8 +1191,8 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
 #define RTMI_LAUNCH_SHADE_CANDIDATES(kernel)                                                                              \
   hipLaunchKernelGGL(kernel, dim3(sc->exact_grid), dim3(256), 0, st, shc, sc->dev, sc->top_args, (const f2*)sc->d_trec, \
                      (const float*)sc->d_gst2, (const int*)sc->groups[0].d_slot_pos, sc->d_sargs + gi, sc->wb.rgb, par)
-          if (ext) {
-            RTMI_LAUNCH_SHADE_CANDIDATES((k_shade_candidates<false, false, false, true>));  // queue every intersection
+          if (ext) {  // every intersection goes to the shade queue
+            hipLaunchKernelGGL(k_queue_candidates, dim3(sc->exact_grid), dim3(256), 0, st, shc, sc->dev, sc->d_sargs + gi, par);
           } else if (nearest) {
             if (has_top_runs) RTMI_LAUNCH_SHADE_CANDIDATES((k_shade_candidates<true, false, true>));
             else if (inert) RTMI_LAUNCH_SHADE_CANDIDATES((k_shade_candidates<false, true, true>));
@@ -1229,13 +1229,15 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
   hipLaunchKernelGGL(kernel, dim3(std::min(grid, 4 * sc->exact_grid)), dim3(256), 0, st, shc, sc->dev, sc->top_args,         \
                      (const f2*)sc->d_trec, (const float*)sc->d_gst2, (const int*)sc->groups[0].d_slot_pos, sc->wb.dirs,     \
                      sc->wb.tval, sc->wb.q_shade, &sc->wb.cnt->q_shade, sc->wb.hit_id, sc->wb.rgb, sc->wb.cnt)
-#define RTMI_LAUNCH_TRACE_REPLAY(NEAREST)                                                                                    \
+#define RTMI_LAUNCH_TRACE_REPLAY(NEAREST, ...)                                                                              \
   do {                                                                                                                      \
-    /* tri_hit and q_top are free once k_resolve_top has run: they carry the recorded outcomes */                           \
-    hipLaunchKernelGGL((k_trace_top<NEAREST>), dim3(std::min(grid, 4 * sc->exact_grid)), dim3(256), 0, st, shc, sc->dev,    \
-                       sc->top_args, (const f2*)sc->d_trec, (const float*)sc->d_gst2, (const int*)sc->groups[0].d_slot_pos, \
-                       sc->wb.dirs, sc->wb.tval, sc->wb.q_shade, &sc->wb.cnt->q_shade, sc->wb.hit_id, sc->wb.rgb,           \
-                       sc->wb.cnt, sc->wb.tri_hit, (unsigned*)sc->wb.q_top);                                                \
+    /* tri_hit and q_top are free once the searches have run: they carry the recorded outcomes */                           \
+    hipLaunchKernelGGL((k_trace_top<NEAREST, __VA_ARGS__>), dim3(std::min(grid, 4 * sc->exact_grid)), dim3(256), 0, st, shc, \
+                       sc->dev, sc->top_args, (const f2*)sc->d_trec, (const float*)sc->d_gst2,                              \
+                       (const int*)sc->groups[0].d_slot_pos, sc->wb.dirs, sc->wb.tval, sc->wb.q_shade,                      \
+                       &sc->wb.cnt->q_shade, sc->wb.hit_id, sc->wb.rgb, sc->wb.cnt, sc->wb.tri_hit,                         \
+                       (unsigned*)sc->wb.q_top, ext_args, (const f2*)sc->d_brec, (const float*)sc->d_bgst2,                 \
+                       (const int*)sc->d_bslot_pos, (const int*)sc->d_bmembers, (const int*)sc->d_bowner);                  \
     hipLaunchKernelGGL((k_shade_replay<NEAREST>), dim3(std::min(grid, 4 * sc->exact_grid)), dim3(256), 0, st, shc, sc->dev, \
                        sc->top_args, (const f2*)sc->d_trec, (const float*)sc->d_gst2, (const int*)sc->groups[0].d_slot_pos, \
                        sc->wb.dirs, sc->wb.tval, sc->wb.q_shade, &sc->wb.cnt->q_shade, sc->wb.hit_id, sc->wb.rgb,           \
@@ -1247,12 +1249,19 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
                      ext_args, (const f2*)sc->d_brec, (const float*)sc->d_bgst2, (const int*)sc->d_bslot_pos,               \
                      (const int*)sc->d_bmembers, (const int*)sc->d_bowner, sc->wb.dirs, sc->wb.tval, sc->wb.q_shade,         \
                      &sc->wb.cnt->q_shade, sc->wb.hit_id, sc->wb.rgb, sc->wb.cnt)
-      if (ext) {
+      if (ext && !nearest && trace_then_shade() && sc->dev.n_lights <= TRACE_MAX_LIGHTS) {
+        // the recorder without the walks that cannot happen on this scene and frame
+        const bool enter = (ext_flags & RTMI_FLAG_SHADOWS_ENTER_BOUNDED) && ext_args.n_bounded > 0;
+        if (has_top_runs && enter) RTMI_LAUNCH_TRACE_REPLAY(false, true, true, true);
+        else if (has_top_runs) RTMI_LAUNCH_TRACE_REPLAY(false, true, true, false);
+        else if (enter) RTMI_LAUNCH_TRACE_REPLAY(false, true, false, true);
+        else RTMI_LAUNCH_TRACE_REPLAY(false, true, false, false);
+      } else if (ext) {
         if (nearest) RTMI_LAUNCH_SHADE_EXT(true);
         else RTMI_LAUNCH_SHADE_EXT(false);
       } else if (has_top_runs && trace_then_shade() && sc->dev.n_lights <= TRACE_MAX_LIGHTS) {
-        if (nearest) RTMI_LAUNCH_TRACE_REPLAY(true);
-        else RTMI_LAUNCH_TRACE_REPLAY(false);
+        if (nearest) RTMI_LAUNCH_TRACE_REPLAY(true, false);
+        else RTMI_LAUNCH_TRACE_REPLAY(false, false);
       } else if (nearest) {
         if (has_top_runs) RTMI_LAUNCH_SHADE((k_shade<true, true>));
         else RTMI_LAUNCH_SHADE((k_shade<false, true>));

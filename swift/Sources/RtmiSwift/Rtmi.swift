@@ -97,17 +97,28 @@ public func raytraceWorld(camera: V3, cameraDirection: V3, focalLength: Double, 
                   imageHeight: imageHeight, ambientLight: ambientLight, scene: scene, outputBitmap: &outputBitmap, pixelDone: pixelDone)
 }
 
+/// What the library offers beyond the reference's behaviour; everything off = the reference.
+public struct RenderExtensions {
+    public var nearestHit = false           // RTMI_HIT_NEAREST: intersections.min(by: parameter) instead of intersections[0]
+    public var shadowMaxDistance = false    // RTMI_FLAG_SHADOW_MAX_DISTANCE: only what lies before the light casts a shadow
+    public var shadowsEnterBounded = false  // RTMI_FLAG_SHADOWS_ENTER_BOUNDED: the TODO at RayTracingFunctions.swift:240
+    public init() {}
+}
+
 /// The same frame for a scene that is already resident on the GPU.
 public func raytraceWorld(camera: V3, cameraDirection: V3, focalLength: Double, imageWidth: Int, imageHeight: Int,
                           pixelSubdivision: Double = 1, ambientLight: Color, scene: RtmiScene,
-                          outputBitmap: inout [UInt8], pixelDone: (() -> Void)? = nil) {
+                          outputBitmap: inout [UInt8], pixelDone: (() -> Void)? = nil,
+                          extensions: RenderExtensions = RenderExtensions()) {
     var cam = rtmi_camera(pos: tuple(camera), dir: tuple(cameraDirection), focal_length: focalLength)
     var p = rtmi_params()
     p.width = Int32(imageWidth)
     p.height = Int32(imageHeight)
     p.pixel_subdivision = pixelSubdivision  // :170 hard-codes 1; 0.5 = 4 samples per pixel, 0.25 = 16
     p.ambient = tuple(ambientLight)
-    p.hit_policy = Int32(RTMI_HIT_LIST_ORDER.rawValue)
+    p.hit_policy = Int32((extensions.nearestHit ? RTMI_HIT_NEAREST : RTMI_HIT_LIST_ORDER).rawValue)
+    p.flags = (extensions.shadowMaxDistance ? RTMI_FLAG_SHADOW_MAX_DISTANCE : 0) |
+              (extensions.shadowsEnterBounded ? RTMI_FLAG_SHADOWS_ENTER_BOUNDED : 0)
     p.search = Int32(RTMI_SEARCH_CONE_TREE.rawValue)
     var counters = rtmi_counters()
     let rc = outputBitmap.withUnsafeMutableBufferPointer { rtmi_render(scene.handle, &cam, &p, $0.baseAddress, nil, &counters) }

@@ -72,5 +72,12 @@ def shadow_extension_cases(bounding_sphere):
                                triangles=np.concatenate([company.triangles, wall]),
                                objects=np.concatenate([company.objects, scenes.sphere_object((3.6, 0.5, 0.6), 0.8, 0),
                                                        scenes.light_object(0), scenes.triangles_object(n, 2)]))
+    # the first half of a mesh listed by two bounding spheres, the second of them smaller than what it lists (a shadow
+    # ray that misses that sphere does not test its children, wherever they are) and carrying a material
+    shared = scenes.mesh_scene(1, "B", 2, bounding_sphere=bounding_sphere)
+    shared.triangles["material"] = 0
+    half = len(shared.triangles) // 2
+    shared.objects = np.concatenate([shared.objects, scenes.sphere_object((0.35, 0.3, 0.2), 0.55, 0, bounding=True, first=0, count=half)])
     return [(bounded, scenes.make_camera(**scenes.MESH_CAMERA)),
-            (company, scenes.make_camera((0.8, 0.9, 5.0), (-0.05, -0.12, -1.0), 7.0))]
+            (company, scenes.make_camera((0.8, 0.9, 5.0), (-0.05, -0.12, -1.0), 7.0)),
+            (shared, scenes.make_camera((0.4, 0.2, 4.5), (-0.05, -0.03, -1.0), 9.0))]
