@@ -120,6 +120,7 @@ struct RenderExtensions {
   bool nearestHit = false;            // RTMI_HIT_NEAREST: intersections.min(by: parameter) instead of intersections[0]
   bool shadowMaxDistance = false;     // RTMI_FLAG_SHADOW_MAX_DISTANCE: only what lies before the light casts a shadow
   bool shadowsEnterBounded = false;   // RTMI_FLAG_SHADOWS_ENTER_BOUNDED: the TODO at RayTracingFunctions.swift:240
+  bool reflectionsEnterBounded = false;  // RTMI_FLAG_REFLECTIONS_ENTER_BOUNDED: mirrors show bounded meshes
 };
 
 inline void raytraceWorld(v3d camera, v3d cameraDirection, double focalLength, int /*imageWidthPixels*/,
@@ -205,7 +206,8 @@ inline void raytraceWorld(v3d camera, v3d cameraDirection, double focalLength, i
   p.ambient[0] = ambientLight.red; p.ambient[1] = ambientLight.green; p.ambient[2] = ambientLight.blue;
   p.hit_policy = extensions.nearestHit ? RTMI_HIT_NEAREST : RTMI_HIT_LIST_ORDER;
   p.flags = (extensions.shadowMaxDistance ? RTMI_FLAG_SHADOW_MAX_DISTANCE : 0) |
-            (extensions.shadowsEnterBounded ? RTMI_FLAG_SHADOWS_ENTER_BOUNDED : 0);
+            (extensions.shadowsEnterBounded ? RTMI_FLAG_SHADOWS_ENTER_BOUNDED : 0) |
+            (extensions.reflectionsEnterBounded ? RTMI_FLAG_REFLECTIONS_ENTER_BOUNDED : 0);
   rtmi_counters counters{};
   rc = rtmi_render(scene, &cam, &p, outputBitmap.data(), nullptr, &counters);
   rtmi_scene_destroy(scene);

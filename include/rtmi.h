@@ -149,7 +149,7 @@ typedef struct {
  * same with and without the flag. */
 #define RTMI_FLAG_NO_RAY_STATISTICS 1
 
-/* Two extensions to the shadow test, both off by default and NOT the reference's behaviour
+/* Extensions to the secondary rays, all off by default and NOT the reference's behaviour.  Two to the shadow test
  * (RayTracingFunctions.swift:234-243 traces a shadow ray against the top-level list only and lets every
  * intersection of a non-bounding object block the light, wherever it lies along the ray):
  * RTMI_FLAG_SHADOW_MAX_DISTANCE    an intersection blocks the light only if its parameter is smaller than the
@@ -159,13 +159,19 @@ typedef struct {
  * RTMI_FLAG_SHADOWS_ENTER_BOUNDED  a shadow ray that intersects a bounding sphere is traced against the sphere's
  *                                  children as well, and a child that is hit blocks the light: the reference's own
  *                                  "TODO seems like I'm forgetting to intersect with shapes inside the bounding
- *                                  shape" (:240).  Reflection rays are unchanged.
- * With either flag every hit of a frame is shaded from a queue after the search, all its secondary rays traced
+ *                                  shape" (:240).
+ * and one to the reflection ray (:207-224), which in the reference sees a bounded mesh as its bounding sphere only:
+ * RTMI_FLAG_REFLECTIONS_ENTER_BOUNDED  a reflection ray whose intersection (intersections[0], or the nearest under
+ *                                  RTMI_HIT_NEAREST) is a bounding sphere goes on to the sphere's children and takes
+ *                                  their first intersection, or none -- what raytracePixels does for the primary ray
+ *                                  (:85-93).  A bounded mesh then shows in mirrors, itself included.
+ * With any of the three every hit of a frame is shaded from a queue after the search, all its secondary rays traced
  * (RTMI_FLAG_NO_RAY_STATISTICS has no effect), and rtmi_render_device_noalloc refuses the frame
- * (RTMI_ERR_UNSUPPORTED): the first frame that asks for RTMI_FLAG_SHADOWS_ENTER_BOUNDED builds a bounding-sphere
+ * (RTMI_ERR_UNSUPPORTED): the first frame that asks for one of the ..._ENTER_BOUNDED flags builds a bounding-sphere
  * tree over the children of all bounding spheres and keeps it with the scene. */
 #define RTMI_FLAG_SHADOW_MAX_DISTANCE 2
 #define RTMI_FLAG_SHADOWS_ENTER_BOUNDED 4
+#define RTMI_FLAG_REFLECTIONS_ENTER_BOUNDED 8
 
 /* Work and timing counters of one render call. */
 typedef struct {

@@ -417,7 +417,12 @@ static rgb calculate_lighting(const rtmi_scene_desc* s, const list_stats* ls, co
     rgb contribution = {0.0, 0.0, 0.0};
     isect rh;
     tl->rays_reflection += 1;
-    if (trace_top(s, ls, surface_point, reflection, &rh, NULL, tl, nearest, INFINITY, 0)) {
+    int have = trace_top(s, ls, surface_point, reflection, &rh, NULL, tl, nearest, INFINITY, 0);
+    /* extension (RTMI_FLAG_REFLECTIONS_ENTER_BOUNDED): a reflection ray whose intersection is a bounding sphere goes on
+     * to the sphere's children, as the primary ray does at RTF:85-93 -- their first intersection, or nothing */
+    if (have && (flags & RTMI_FLAG_REFLECTIONS_ENTER_BOUNDED) && rh.is_bounding)
+      have = trace_children(s, &s->objects[rh.object], rh.object, surface_point, reflection, &rh, tl, nearest);
+    if (have) {
       contribution = calculate_lighting(s, ls, &rh, ambient, surface_point, 0, tl, nearest, flags);
     }
     I.r = I.r + contribution.r;

@@ -292,7 +292,7 @@ def shadow_blockers(hits, origin, direction, light, max_distance, enter_bounded)
 
 
 def calculate_lighting(isect, ambient_light, lights, camera, objects, reflect=True, counters=None, nearest=False,
-                       shadow_max_distance=False, shadows_enter_bounded=False):  # :182-271
+                       shadow_max_distance=False, shadows_enter_bounded=False, reflections_enter_bounded=False):  # :182-271
     surface_point = isect.point
     material = isect.object.material
     intensity = RGB(0, 0, 0)
@@ -311,9 +311,15 @@ def calculate_lighting(isect, ambient_light, lights, camera, objects, reflect=Tr
         if counters is not None:
             counters["rays_reflection"] += 1
         trace_ray(surface_point, reflection, objects, hits)
-        if hits:
-            contribution = calculate_lighting(pick(hits, nearest), ambient_light, lights, surface_point, objects, False, counters, nearest,
-                                              shadow_max_distance, shadows_enter_bounded)
+        seen = pick(hits, nearest) if hits else None
+        if seen is not None and reflections_enter_bounded and seen.object.isBounding:
+            # extension: the mirror shows what is inside the bounding sphere, found the way raytracePixels finds it (:85-93)
+            inner = []
+            trace_ray(surface_point, reflection, seen.object.getBoundedIntersectables(), inner)
+            seen = pick(inner, nearest) if inner else None
+        if seen is not None:
+            contribution = calculate_lighting(seen, ambient_light, lights, surface_point, objects, False, counters, nearest,
+                                              shadow_max_distance, shadows_enter_bounded, reflections_enter_bounded)
         intensity.add(contribution)
     for light in lights:
         point_to_light = normalize(light.location - surface_point)
@@ -384,7 +390,7 @@ def to_u8(c):
 
 
 def raytrace_world(camera, camera_direction, focal_length, width, height, subdivision, ambient, lights, objects, nearest=False,
-                   shadow_max_distance=False, shadows_enter_bounded=False):
+                   shadow_max_distance=False, shadows_enter_bounded=False, reflections_enter_bounded=False):
     """raytraceWorld + raytracePixels (:145-180, :59-114) with the frame size and the subdivision as arguments.
     Returns (rgba rows as nested lists [H][W][4] or None where nothing is written, hit ids [H][W][spp], counters)."""
     center = camera + camera_direction.times(focal_length)
@@ -420,7 +426,7 @@ def raytrace_world(camera, camera_direction, focal_length, width, height, subdiv
                 i1 = pick(inner, nearest)
             counters["primary_hits"] += 1
             values.append(calculate_lighting(i1, ambient, lights, camera, objects, True, counters, nearest,
-                                             shadow_max_distance, shadows_enter_bounded))
+                                             shadow_max_distance, shadows_enter_bounded, reflections_enter_bounded))
             ids.append(i1.object.ident)
         avg = average(values)
         rgba[y][x] = [to_u8(avg.red), to_u8(avg.green), to_u8(avg.blue), 255]
@@ -470,7 +476,8 @@ def render(data, camera, params):
     amb = RGB(*[float(x) for x in params.ambient])
     return raytrace_world(V3(*camera.pos), V3(*camera.dir), float(camera.focal_length), params.width, params.height,
                           float(params.pixel_subdivision), amb, lights, objects, nearest=params.hit_policy == 1,
-                          shadow_max_distance=bool(params.flags & 2), shadows_enter_bounded=bool(params.flags & 4))
+                          shadow_max_distance=bool(params.flags & 2), shadows_enter_bounded=bool(params.flags & 4),
+                          reflections_enter_bounded=bool(params.flags & 8))
 
 
 # ---- ObjLoader.swift, ViewController.swift:107-120 ----------------------------------------------

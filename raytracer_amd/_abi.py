@@ -77,6 +77,7 @@ class Counters(C.Structure):
 RTMI_FLAG_NO_RAY_STATISTICS = 1
 RTMI_FLAG_SHADOW_MAX_DISTANCE = 2
 RTMI_FLAG_SHADOWS_ENTER_BOUNDED = 4
+RTMI_FLAG_REFLECTIONS_ENTER_BOUNDED = 8
 
 RTMI_SEARCH_CONE_TREE = 0
 RTMI_SEARCH_LIST_SCAN = 1

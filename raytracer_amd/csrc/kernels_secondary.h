@@ -83,7 +83,7 @@ __device__ inline TopTreeRef make_top_tree(const TopTreeArgs& a, const f2* rec, 
 }
 
 // The shadow-ray extensions (RTMI_FLAG_SHADOW_MAX_DISTANCE, RTMI_FLAG_SHADOWS_ENTER_BOUNDED) walk trees of the same
-// layout over other member lists, with two more conditions on a hit.  members/n_members/c0 replace
+// layout over other member lists, with more conditions on a hit.  members/n_members/c0 replace
 // SceneDev::top_group/n_top_tris/c0; a hit counts only below max_t; with member_owner (member -> the bounding
 // sphere that lists it) a hit counts only if the ray intersects that sphere at all, which is when the
 // extension tests the sphere's children.
@@ -93,6 +93,8 @@ struct WalkExt {
   long long n_members;
   double c0[3];
   double max_t;
+  int only_owner;           // >= 0 (with member_owner): only the members of this bounding sphere count, and the ray is
+                            // known to intersect it (RTMI_FLAG_REFLECTIONS_ENTER_BOUNDED)
 };
 
 // A general-origin ray (reflection or shadow ray) against ALL top-level triangles: the ordinal of
@@ -207,10 +209,12 @@ __device__ inline int top_tree_trace(const SceneDev& sc, const TopTreeRef& T, d3
           const rtmi_triangle& tr = sc.tris[ti];
           double t;
           d3 P;
-          bool hit = rtx::tri_hit(rtx::ld3(tr.v[0]), rtx::ld3(tr.v[1]), rtx::ld3(tr.v[2]), sc.planes[ti], o, d, &t, &P);
+          bool mine = true;
+          if constexpr (EXT) mine = !(WX->member_owner && WX->only_owner >= 0) || WX->member_owner[g] == WX->only_owner;
+          bool hit = mine && rtx::tri_hit(rtx::ld3(tr.v[0]), rtx::ld3(tr.v[1]), rtx::ld3(tr.v[2]), sc.planes[ti], o, d, &t, &P);
           if constexpr (EXT) {
             hit = hit && t < WX->max_t;
-            if (hit && WX->member_owner) {
+            if (hit && WX->member_owner && WX->only_owner < 0) {
               const rtmi_object& ob = sc.objects[min(max(WX->member_owner[g], 0), sc.n_objects - 1)];
               hit = rtx::sphere_any(rtx::ld3(ob.center), ob.radius, o, d);
             }
@@ -346,11 +350,16 @@ __device__ inline bool trace_top_secondary(const SceneDev& sc, const TopTreeRef&
 // instruction), and a child is entered if some lane passes.  At a leaf the per-triangle cascade
 // of k_pack_general follows, then rtx::tri_hit in FP64.  Called from divergent shading code: the
 // wave-level votes only see the lanes that are tracing.
+// EXT: the tree and the member filter of *WX (see WalkExt; only_owner walks).
+template <bool EXT = false>
 __device__ inline int top_tree_trace_nearest(const SceneDev& sc, const TopTreeRef& T, d3 o, d3 d, bool any_only, double* t_out,
-                                     d3* P_out, tally_t* n_tests) {
+                                     d3* P_out, tally_t* n_tests, const WalkExt* WX = nullptr) {
   const bool nearest = !any_only;  // the hit with the smallest parameter instead of the lowest ordinal
   double best_t = 0.0;
-  const float ox = (float)(o.x - sc.c0[0]), oy = (float)(o.y - sc.c0[1]), oz = (float)(o.z - sc.c0[2]);
+  const double c0x = EXT ? WX->c0[0] : sc.c0[0], c0y = EXT ? WX->c0[1] : sc.c0[1], c0z = EXT ? WX->c0[2] : sc.c0[2];
+  const long long n_members = EXT ? WX->n_members : sc.n_top_tris;
+  const int* members = EXT ? WX->members : sc.top_group;
+  const float ox = (float)(o.x - c0x), oy = (float)(o.y - c0y), oz = (float)(o.z - c0z);
   const float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
   const float ndo = -(dx * ox + dy * oy + dz * oz);
   const float noo = -(ox * ox + oy * oy + oz * oz);
@@ -404,7 +413,7 @@ __device__ inline int top_tree_trace_nearest(const SceneDev& sc, const TopTreeRe
         bool cand = live && !(u < 0.0f);
         if (!__any(cand)) continue;
         const int g = T.slot_pos[ri * 8 + pr * 2 + h];  // top-level ordinal
-        if ((unsigned)g >= (unsigned)sc.n_top_tris) continue;  // padding slot (its sphere passes nothing; belt and braces)
+        if ((unsigned)g >= (unsigned)n_members) continue;  // padding slot (its sphere passes nothing; belt and braces)
         // a later list position cannot replace the hit (under the nearest-hit policy any triangle can)
         cand = cand && (any_only ? best == 0x7fffffff : (nearest || g < best));
         if (!__any(cand)) continue;
@@ -425,11 +434,13 @@ __device__ inline int top_tree_trace_nearest(const SceneDev& sc, const TopTreeRe
         }
         if (!__any(cand)) continue;
         if (cand) {
-          const int ti = min(max(sc.top_group[g], 0), sc.n_tris - 1);  // the clamps never bind
+          const int ti = min(max(members[g], 0), sc.n_tris - 1);  // the clamps never bind
           const rtmi_triangle& tr = sc.tris[ti];
           double t;
           d3 P;
-          if (rtx::tri_hit(rtx::ld3(tr.v[0]), rtx::ld3(tr.v[1]), rtx::ld3(tr.v[2]), sc.planes[ti], o, d, &t, &P)) {
+          bool mine = true;
+          if constexpr (EXT) mine = !(WX->member_owner && WX->only_owner >= 0) || WX->member_owner[g] == WX->only_owner;
+          if (mine && rtx::tri_hit(rtx::ld3(tr.v[0]), rtx::ld3(tr.v[1]), rtx::ld3(tr.v[2]), sc.planes[ti], o, d, &t, &P)) {
             if (!nearest || best == 0x7fffffff || t < best_t || (t == best_t && g < best)) {
               best = g;
               best_t = t;
@@ -555,7 +566,7 @@ __device__ inline bool trace_top_secondary_nearest(const SceneDev& sc, const Top
 // over the children of ALL bounding spheres of the scene (built when a frame first asks for
 // RTMI_FLAG_SHADOWS_ENTER_BOUNDED; same layout as the tree of the top-level runs).
 struct ExtArgs {
-  int flags;             // RTMI_FLAG_SHADOW_MAX_DISTANCE | RTMI_FLAG_SHADOWS_ENTER_BOUNDED
+  int flags;             // RTMI_FLAG_SHADOW_MAX_DISTANCE | RTMI_FLAG_SHADOWS_ENTER_BOUNDED | RTMI_FLAG_REFLECTIONS_ENTER_BOUNDED
   int pad;
   long long n_bounded;   // members of the bounded tree (0: none, or the flag is off)
   double c0[3];          // centre its FP32 coordinates are relative to
@@ -610,6 +621,7 @@ __device__ inline bool shadow_blocked_ext(const SceneDev& sc, const TopTreeRef& 
     w.members = sc.top_group; w.member_owner = nullptr; w.n_members = sc.n_top_tris;
     w.c0[0] = sc.c0[0]; w.c0[1] = sc.c0[1]; w.c0[2] = sc.c0[2];
     w.max_t = max_t;
+    w.only_owner = -1;
     if (top_tree_trace<true>(sc, tt, o, d, true, &t, &P, n_tests, &w) >= 0) return true;
   }
   if (WALK_BOUNDED && (ext.flags & RTMI_FLAG_SHADOWS_ENTER_BOUNDED) && ext.n_bounded > 0) {
@@ -617,7 +629,31 @@ __device__ inline bool shadow_blocked_ext(const SceneDev& sc, const TopTreeRef& 
     w.members = ext.members; w.member_owner = ext.member_owner; w.n_members = ext.n_bounded;
     w.c0[0] = ext.c0[0]; w.c0[1] = ext.c0[1]; w.c0[2] = ext.c0[2];
     w.max_t = max_t;
+    w.only_owner = -1;
     if (top_tree_trace<true>(sc, ext.bounded, o, d, true, &t, &P, n_tests, &w) >= 0) return true;
   }
   return false;
+}
+
+// RTMI_FLAG_REFLECTIONS_ENTER_BOUNDED: the reflection ray's intersection *h is the bounding sphere objects[k]; its
+// children are searched the way raytracePixels searches them for a primary ray (RTF:85-93): their first
+// intersection in list order (the nearest under that policy) replaces *h, or the ray has hit nothing.
+template <bool NEAREST>
+__device__ inline bool reflection_enters_bounded(const SceneDev& sc, const ExtRef& ext, int k, d3 o, d3 d, Hit* h, tally_t* n_tests) {
+  WalkExt w;
+  w.members = ext.members; w.member_owner = ext.member_owner; w.n_members = ext.n_bounded;
+  w.c0[0] = ext.c0[0]; w.c0[1] = ext.c0[1]; w.c0[2] = ext.c0[2];
+  w.max_t = INFINITY;
+  w.only_owner = k;
+  double t;
+  d3 P;
+  int g;
+  if constexpr (NEAREST) g = top_tree_trace_nearest<true>(sc, ext.bounded, o, d, false, &t, &P, n_tests, &w);
+  else g = top_tree_trace<true>(sc, ext.bounded, o, d, false, &t, &P, n_tests, &w);
+  if (g < 0) return false;
+  const int ti = min(max(ext.members[g], 0), sc.n_tris - 1);
+  const TriPlane pl = sc.planes[ti];
+  h->P = P; h->n = rtx::mk(pl.nx, pl.ny, pl.nz); h->t = t; h->has_normal = 1; h->n_unit = 1;
+  h->material = sc.tris[ti].material; h->id = ti;
+  return true;
 }

@@ -101,9 +101,11 @@ struct TraceRec {
 __device__ inline unsigned shadow_key(int light, int depth) { return (unsigned)(light + TRACE_MAX_LIGHTS * depth) & 31u; }
 
 // The reflection ray (RTF:212-216): its first intersection under the frame's hit policy.
-template <int MODE, bool HAS_TOP, bool NEAREST>
+// EXT with EXT_ENTER: under RTMI_FLAG_REFLECTIONS_ENTER_BOUNDED an intersection that is a bounding sphere is replaced by
+// what the ray finds among the sphere's children (reflection_enters_bounded).
+template <int MODE, bool HAS_TOP, bool NEAREST, bool EXT = false, bool EXT_ENTER = true>
 __device__ __forceinline__ bool traced_first(const SceneDev& sc, const TopTreeRef& tt, d3 o, d3 d, Hit* h, tally_t* n_tests,
-                                             TraceRec* rec) {
+                                             TraceRec* rec, const ExtRef* ext = nullptr) {
   if constexpr (MODE == TRACE_REPLAY) {
     const int id = rec->id;
     if (id == -1) return false;
@@ -127,7 +129,14 @@ __device__ __forceinline__ bool traced_first(const SceneDev& sc, const TopTreeRe
     return true;
   } else {
     bool anb;
-    const bool found = trace_secondary<HAS_TOP, NEAREST>(sc, tt, o, d, true, h, &anb, n_tests);
+    bool found = trace_secondary<HAS_TOP, NEAREST>(sc, tt, o, d, true, h, &anb, n_tests);
+    if constexpr (EXT && EXT_ENTER) {
+      // (a scene whose bounding spheres are all empty has no tree: the walk then visits nothing and the ray has hit nothing)
+      if (found && h->id <= -2 && (ext->flags & RTMI_FLAG_REFLECTIONS_ENTER_BOUNDED)) {
+        const int k = min(-2 - h->id, sc.n_objects - 1);
+        if (sc.objects[k].kind == RTMI_BOUNDING_SPHERE) found = reflection_enters_bounded<NEAREST>(sc, *ext, k, o, d, h, n_tests);
+      }
+    }
     if constexpr (MODE == TRACE_RECORD) {
       rec->id = found ? h->id : -1;
       rec->t = found ? h->t : 0.0;
@@ -165,7 +174,7 @@ __device__ __forceinline__ bool traced_any(const SceneDev& sc, const TopTreeRef&
 // EXT (with neither LEAN nor INERT; tracing or recording, a replay does not care how the outcomes came about): the
 // shadow test of the light loop follows *ext
 // (RTMI_FLAG_SHADOW_MAX_DISTANCE, RTMI_FLAG_SHADOWS_ENTER_BOUNDED; shadow_blocked_ext) instead of RTF:236-243.
-// EXT_ENTER false: the frame does not ask for RTMI_FLAG_SHADOWS_ENTER_BOUNDED (the walk of the bounded tree is left out).
+// EXT_ENTER false: the frame asks for neither ..._ENTER_BOUNDED flag (the walks of the bounded tree are left out).
 template <bool REFLECT, bool HAS_TOP, bool LEAN = false, bool INERT = false, bool NEAREST = false, int MODE = TRACE_LIVE,
           bool EXT = false, bool EXT_ENTER = true>
 __device__ __forceinline__ RGBd calculate_lighting(const SceneDev& sc, const TopTreeRef& tt, const ShadeConst& fc, const Hit& is, d3 camera,
@@ -228,7 +237,7 @@ __device__ __forceinline__ RGBd calculate_lighting(const SceneDev& sc, const Top
       *n_tests += nt;
     } else {
       *n_refl += 1;
-      if (traced_first<MODE, HAS_TOP, NEAREST>(sc, tt, surface_point, reflection, &rh, n_tests, rec)) {
+      if (traced_first<MODE, HAS_TOP, NEAREST, EXT, EXT_ENTER>(sc, tt, surface_point, reflection, &rh, n_tests, rec, ext)) {
         contribution = calculate_lighting<false, HAS_TOP, false, false, NEAREST, MODE, EXT, EXT_ENTER>(
             sc, tt, fc, rh, surface_point, n_refl, n_shadow, n_tests, n_elided, nullptr, rec, ext);
       }

@@ -744,7 +744,7 @@ static int32_t pack_group(rtmi_scene* sc, TriGroup& g, d3 cam) {
 // record fetches whatever the number of rays it carries, and a small batch (a 1080p frame at 4 samples per pixel is
 // 8 M samples) has too few waves at 4 rays per lane to hide that chain -- measured on the 1.3 M-triangle mesh at
 // 1080p: 1.40 ms per frame with 2 rays per lane, 1.67 with 4; at 4K and 16 samples per pixel 4 wins by 11 %.
-// RTMI_FLAG_SHADOWS_ENTER_BOUNDED: the bounding-sphere tree over the children of all bounding spheres (the same
+// RTMI_FLAG_SHADOWS_ENTER_BOUNDED, RTMI_FLAG_REFLECTIONS_ENTER_BOUNDED: the bounding-sphere tree over the children of all bounding spheres (the same
 // construction as the top-level runs' tree in scene_create_impl), built when a frame first asks for the flag.
 // The triangles come back from the device: the caller's arrays are gone by now.  The scene's stream is idle.
 static int32_t ensure_bounded_tree(rtmi_scene* sc) {
@@ -847,13 +847,14 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
   }
   if (p->hit_policy != RTMI_HIT_LIST_ORDER && p->hit_policy != RTMI_HIT_NEAREST) return RTMI_ERR_UNSUPPORTED;
   if (p->search != RTMI_SEARCH_CONE_TREE && p->search != RTMI_SEARCH_LIST_SCAN) return RTMI_ERR_INVALID_ARGUMENT;
-  if (p->flags & ~(RTMI_FLAG_NO_RAY_STATISTICS | RTMI_FLAG_SHADOW_MAX_DISTANCE | RTMI_FLAG_SHADOWS_ENTER_BOUNDED))
-    return RTMI_ERR_INVALID_ARGUMENT;
-  // the shadow-ray extensions: every hit is shaded from the shade queue by k_shade_ext
-  const int ext_flags = p->flags & (RTMI_FLAG_SHADOW_MAX_DISTANCE | RTMI_FLAG_SHADOWS_ENTER_BOUNDED);
+  constexpr int EXT_FLAGS = RTMI_FLAG_SHADOW_MAX_DISTANCE | RTMI_FLAG_SHADOWS_ENTER_BOUNDED | RTMI_FLAG_REFLECTIONS_ENTER_BOUNDED;
+  constexpr int ENTER_FLAGS = RTMI_FLAG_SHADOWS_ENTER_BOUNDED | RTMI_FLAG_REFLECTIONS_ENTER_BOUNDED;
+  if (p->flags & ~(RTMI_FLAG_NO_RAY_STATISTICS | EXT_FLAGS)) return RTMI_ERR_INVALID_ARGUMENT;
+  // the secondary-ray extensions: every hit is shaded from the shade queue
+  const int ext_flags = p->flags & EXT_FLAGS;
   const bool ext = ext_flags != 0;
   if (ext && sc->no_alloc) {
-    g_last_error = "rtmi_render_device_noalloc: the shadow-ray extension flags are not supported";
+    g_last_error = "rtmi_render_device_noalloc: the secondary-ray extension flags are not supported";
     return RTMI_ERR_UNSUPPORTED;
   }
   const bool use_tree = p->search == RTMI_SEARCH_CONE_TREE;
@@ -899,7 +900,7 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
   }
   HIP_TRY(hipSetDevice(sc->device));
   ExtArgs ext_args{};
-  if (ext_flags & RTMI_FLAG_SHADOWS_ENTER_BOUNDED) {
+  if (ext_flags & ENTER_FLAGS) {
     int32_t rc_b = ensure_bounded_tree(sc);
     if (rc_b) return rc_b;
     ext_args = sc->bounded_args;
@@ -1251,7 +1252,7 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
                      &sc->wb.cnt->q_shade, sc->wb.hit_id, sc->wb.rgb, sc->wb.cnt)
       if (ext && !nearest && trace_then_shade() && sc->dev.n_lights <= TRACE_MAX_LIGHTS) {
         // the recorder without the walks that cannot happen on this scene and frame
-        const bool enter = (ext_flags & RTMI_FLAG_SHADOWS_ENTER_BOUNDED) && ext_args.n_bounded > 0;
+        const bool enter = (ext_flags & ENTER_FLAGS) != 0;
         if (has_top_runs && enter) RTMI_LAUNCH_TRACE_REPLAY(false, true, true, true);
         else if (has_top_runs) RTMI_LAUNCH_TRACE_REPLAY(false, true, true, false);
         else if (enter) RTMI_LAUNCH_TRACE_REPLAY(false, true, false, true);

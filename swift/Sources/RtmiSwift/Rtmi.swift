@@ -102,6 +102,7 @@ public struct RenderExtensions {
     public var nearestHit = false           // RTMI_HIT_NEAREST: intersections.min(by: parameter) instead of intersections[0]
     public var shadowMaxDistance = false    // RTMI_FLAG_SHADOW_MAX_DISTANCE: only what lies before the light casts a shadow
     public var shadowsEnterBounded = false  // RTMI_FLAG_SHADOWS_ENTER_BOUNDED: the TODO at RayTracingFunctions.swift:240
+    public var reflectionsEnterBounded = false  // RTMI_FLAG_REFLECTIONS_ENTER_BOUNDED: mirrors show bounded meshes
     public init() {}
 }
 
@@ -118,7 +119,8 @@ public func raytraceWorld(camera: V3, cameraDirection: V3, focalLength: Double, 
     p.ambient = tuple(ambientLight)
     p.hit_policy = Int32((extensions.nearestHit ? RTMI_HIT_NEAREST : RTMI_HIT_LIST_ORDER).rawValue)
     p.flags = (extensions.shadowMaxDistance ? RTMI_FLAG_SHADOW_MAX_DISTANCE : 0) |
-              (extensions.shadowsEnterBounded ? RTMI_FLAG_SHADOWS_ENTER_BOUNDED : 0)
+              (extensions.shadowsEnterBounded ? RTMI_FLAG_SHADOWS_ENTER_BOUNDED : 0) |
+              (extensions.reflectionsEnterBounded ? RTMI_FLAG_REFLECTIONS_ENTER_BOUNDED : 0)
     p.search = Int32(RTMI_SEARCH_CONE_TREE.rawValue)
     var counters = rtmi_counters()
     let rc = outputBitmap.withUnsafeMutableBufferPointer { rtmi_render(scene.handle, &cam, &p, $0.baseAddress, nil, &counters) }

@@ -113,8 +113,8 @@ def run_one(seed, index, oracle, keep_dir=None, tsan=False):
     nearest = index % 3 == 2 and index % 5 != 4
     if nearest:
         params.hit_policy = _abi.RTMI_HIT_NEAREST
-    if index % 4 == 1:  # every fourth case with the shadow-ray extensions: distance limit, entering bounding spheres, both
-        params.flags = [2, 4, 6][(index // 4) % 3]
+    if index % 4 == 1:  # every fourth case with the secondary-ray extensions: distance limit, shadow / reflection rays entering bounding spheres
+        params.flags = [2, 4, 6, 8, 12, 14][(index // 4) % 6]
     expected = [oracle.render(data, cam, params, threads=1)] * 2
     env = {"EMU_SEED": str(index % 4), "EMU_FILL": str([0xA5, 0, 0xFF, 0x7F][index % 4]), "EMU_CUS": str(1 + index % 3)}
     if index % 5 == 4:  # candidate lists that overflow, frames cut into batches

@@ -98,10 +98,12 @@ def main():
     save("mixed_nearest_3L_64x48", mixed_scene(), dict(pos=(0.5, 0.8, 5.0), direction=(-0.05, -0.12, -1.0), focal_length=8.0),
          64, 48, 0.5, ambient=(0.25, 0.2, 0.3), hit_policy=1)
     # the shadow-ray extensions: RTMI_FLAG_SHADOWS_ENTER_BOUNDED (4) on a non-convex bounded mesh whose triangles carry
-    # a material (its folds then shadow one another), and both flags (6) on the mixed scene
+    # a material (its folds then shadow one another), RTMI_FLAG_REFLECTIONS_ENTER_BOUNDED (8) on the same (its folds then
+    # mirror one another), and both shadow flags (6) on the mixed scene
     folded = scenes.mesh_scene(2, "B", 3, bounding_sphere=oracle.bounding_sphere)
     folded.triangles["material"] = 0
     save("ico2_bounded_shadows_enter_48x40", folded, scenes.MESH_CAMERA, 48, 40, 0.5, flags=4)
+    save("ico2_bounded_reflections_enter_48x40", folded, scenes.MESH_CAMERA, 48, 40, 0.5, flags=8)
     save("mixed_shadow_extensions_3L_64x48", mixed_scene(), dict(pos=(0.5, 0.8, 5.0), direction=(-0.05, -0.12, -1.0), focal_length=8.0),
          64, 48, 0.5, ambient=(0.25, 0.2, 0.3), flags=6)
 

@@ -92,8 +92,8 @@ def main(argv=None):
         nearest = i % 3 == 2
         if nearest:
             params.hit_policy = _abi.RTMI_HIT_NEAREST
-        if i % 4 == 1:  # every fourth case with the shadow-ray extensions: distance limit, entering bounding spheres, both
-            params.flags = [2, 4, 6][(i // 4) % 3]
+        if i % 4 == 1:  # every fourth case with the secondary-ray extensions: distance limit, shadow / reflection rays entering bounding spheres
+            params.flags = [2, 4, 6, 8, 12, 14][(i // 4) % 6]
         if a.extras and i % 4 == 3:  # many lights (more than 16: the shading kernel that traces its own rays)
             rng = np.random.default_rng([a.seed, i, 99])
             n = int(rng.choice([5, 9, 16, 17, 20]))

@@ -78,6 +78,14 @@ def shadow_extension_cases(bounding_sphere):
     shared.triangles["material"] = 0
     half = len(shared.triangles) // 2
     shared.objects = np.concatenate([shared.objects, scenes.sphere_object((0.35, 0.3, 0.2), 0.55, 0, bounding=True, first=0, count=half)])
+    # a sphere beside a bounding sphere that has a material and no children (the only bounding sphere of the scene, so
+    # there is no tree of children at all): the reference shows it in the sphere's mirror, a reflection ray that enters
+    # it finds nothing
+    hollow = scenes.two_sphere_scene()
+    hollow.objects["kind"][1] = 2
+    hollow.objects["first"][1] = 0
+    hollow.objects["count"][1] = 0
     return [(bounded, scenes.make_camera(**scenes.MESH_CAMERA)),
             (company, scenes.make_camera((0.8, 0.9, 5.0), (-0.05, -0.12, -1.0), 7.0)),
-            (shared, scenes.make_camera((0.4, 0.2, 4.5), (-0.05, -0.03, -1.0), 9.0))]
+            (shared, scenes.make_camera((0.4, 0.2, 4.5), (-0.05, -0.03, -1.0), 9.0)),
+            (hollow, scenes.make_camera(**scenes.VC_CAMERA))]

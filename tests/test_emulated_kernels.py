@@ -314,18 +314,22 @@ def test_emulated_lean_shading_hands_over_to_the_full_kernel(emu, oracle_mod, tm
 
 
 @pytest.mark.parametrize("flags", [_abi.RTMI_FLAG_SHADOW_MAX_DISTANCE, _abi.RTMI_FLAG_SHADOWS_ENTER_BOUNDED,
-                                   _abi.RTMI_FLAG_SHADOW_MAX_DISTANCE | _abi.RTMI_FLAG_SHADOWS_ENTER_BOUNDED])
+                                   _abi.RTMI_FLAG_SHADOW_MAX_DISTANCE | _abi.RTMI_FLAG_SHADOWS_ENTER_BOUNDED,
+                                   _abi.RTMI_FLAG_REFLECTIONS_ENTER_BOUNDED, 14])
 def test_emulated_shadow_extensions(emu, oracle_mod, tmp_path, flags):
-    """The two extensions of the shadow test (a distance limit; shadow rays that enter bounding spheres): every hit goes
-    through the shade queue to k_shade_ext, which walks the top-level runs' tree and the tree over the bounded
+    """The extensions of the secondary rays (a distance limit for shadow rays; shadow rays and reflection rays that
+    enter bounding spheres): every hit goes through the shade queue to the recording and replaying kernels (to
+    k_shade_ext under the nearest-hit policy), which walk the top-level runs' tree and the tree over the bounded
     children.  Both searches, both hit policies (the nearest-hit policy with the cone tree only), two frames on one
     scene object (the bounded tree is built by the first)."""
+    changed = 0
     for k, (data, cam) in enumerate(shadow_extension_cases(oracle_mod.bounding_sphere)):
         out = run_case(emu, oracle_mod, tmp_path / f"lo{k}", data, [cam, cam], scenes.make_params(40, 32, 0.5, flags=flags))
         plain = oracle_mod.render(data, cam, scenes.make_params(40, 32, 0.5), threads=4)[0]
-        assert (out["tree"][0][0] != plain).any()  # the flags do change this frame
+        changed += int((out["tree"][0][0] != plain).any(axis=-1).sum())
         run_case(emu, oracle_mod, tmp_path / f"nr{k}", data, [cam],
                  scenes.make_params(40, 32, 0.5, flags=flags, hit_policy=_abi.RTMI_HIT_NEAREST), searches=("tree",))
+    assert changed > 0  # the flags do change these frames
 
 
 def test_emulated_pixels_only_flag_gives_the_same_frame(emu, oracle_mod, tmp_path):

@@ -115,10 +115,11 @@ def test_second_restatement_agrees_on_the_nearest_hit_extension(oracle_mod):
     assert differs > 0  # the extension does change hits on these scenes
 
 
-@pytest.mark.parametrize("flags", [2, 4, 6])
+@pytest.mark.parametrize("flags", [2, 4, 6, 8, 14])
 def test_second_restatement_agrees_on_the_shadow_extensions(oracle_mod, flags):
-    """RTMI_FLAG_SHADOW_MAX_DISTANCE (2) and RTMI_FLAG_SHADOWS_ENTER_BOUNDED (4) in the C oracle against their
-    statement in the Python restatement (shadow_blockers), with both hit policies; each flag must change pixels."""
+    """RTMI_FLAG_SHADOW_MAX_DISTANCE (2), RTMI_FLAG_SHADOWS_ENTER_BOUNDED (4) and RTMI_FLAG_REFLECTIONS_ENTER_BOUNDED (8) in
+    the C oracle against their statement in the Python restatement (shadow_blockers; the reflection branch of
+    calculate_lighting), with both hit policies; each flag must change pixels."""
     changed = 0
     for data, cam in shadow_extension_cases(oracle_mod.bounding_sphere):
         for policy in (0, 1):

@@ -1,4 +1,4 @@
-"""Times the C3 frame (form B, triangles with a material so that shadows show) under the shadow-ray extension flags."""
+"""Times the C3 frame (form B, triangles with a material so that shadows show) under the secondary-ray extension flags."""
 import hashlib
 import sys
 import time
@@ -16,7 +16,7 @@ data.triangles["material"] = 0
 sc = rt.Scene(data, device=0)
 frame = torch.empty((h, w, 4), dtype=torch.uint8, device="cuda:0")
 cam = scenes.make_camera(**scenes.MESH_CAMERA)
-for flags in (0, 2, 4, 6):
+for flags in (0, 2, 4, 6, 8, 14):
     params = scenes.make_params(w, h, 0.25, flags=flags)
     sc.render_device(cam, params, frame.data_ptr())
     torch.cuda.synchronize()
