@@ -364,11 +364,19 @@ def shade_roofline(args, totals, steps, n_lights, inert):
     flops_hit_ref = shade_flops_per_hit(n_lights, False, 1 if args.form == "B" else 0)
     ms_shade = totals["ms_shade"] / steps
     hits = totals["primary_hits"] / steps
+    # On a form-B scene the launch also decides the hit's own (ray, triangle) pair with Triangle.intersections when it is
+    # the ray's only candidate (99.5 % of the hit rays of this mesh; the others were decided by k_search_exact_multi).
+    # The single candidates that turn out to be no hit (2 to 3 % of the candidates) are not counted.
+    decide = FLOPS_PER_TEST if args.form == "B" else 0
+    flops_hit += decide
+    flops_hit_ref += decide
     achieved = hits * flops_hit / (ms_shade * 1e-3) / 1e12 if ms_shade > 0 else 0.0
     # template arguments: <top-level runs, pixels only on an inert scene, nearest-hit policy>
     kernel = ("k_shade_candidates<false, true, false>" if inert else
               ("k_shade_candidates<false, false, false>" if args.form == "B" else "k_trace_top<false>"))
-    bytes_hit = 64  # candidate entry 8 + best position 4 + direction 24 read; hit id 4 + colour 24 written
+    # candidate entry 8 + best position 4 + direction 24 (+ the triangle 72 and its plane 32 where the pair is decided
+    # here) read; hit id 4 + colour 24 written
+    bytes_hit = 64 + (104 if args.form == "B" else 0)
     pmc = pmc_fractions(pmc_kernel(args.config, kernel))
     return {
         "bound": "valu_fp64",
@@ -389,9 +397,11 @@ def shade_roofline(args, totals, steps, n_lights, inert):
                      "achieved": round(hits * bytes_hit / (ms_shade * 1e-3) / 1e9, 1) if ms_shade > 0 else 0.0,
                      "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                      "frac": round(hits * bytes_hit / (ms_shade * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4) if ms_shade > 0 else 0.0},
-        "note": "achieved = shaded hits per launch x the FP64 operations of calculateLighting that the launch has to perform per "
-                "hit (division, sqrt, pow counted as 1; with pixels only on this scene the secondary rays' operations are not "
-                "performed and not counted) / launch time (HIP events on the library's stream).  The reference's arithmetic is "
+        "note": "achieved = shaded hits per launch x the FP64 operations the launch has to perform per hit -- calculateLighting "
+                "(division, sqrt, pow counted as 1; with pixels only on this scene the secondary rays' operations are not "
+                "performed and not counted) plus, on a form-B scene, the 69 of Triangle.intersections for the hit's own pair, "
+                "which this launch decides when it is the ray's only candidate -- / launch time (HIP events on the library's "
+                "stream).  The reference's arithmetic is "
                 "kept bit for bit, and IEEE FP64 division and square root are instruction sequences on this ISA: measured "
                 "(profiles/r02_ubench_fp64.txt) a division occupies a SIMD for 65 cycles per wave, a square root for 90, a "
                 "multiply-add for 5; the 7 normalizations of a hit alone are 7 x 216 cycles.  `executed` holds what the "

@@ -36,6 +36,15 @@ __device__ __forceinline__ unsigned long long wave_mask(bool p) { return __built
 __device__ inline unsigned long long wave_mask(bool p) { return __ballot(p); }
 #endif
 
+// A load of a word that other work-items of the launch may be changing with atomic operations at the same time
+// (the value read is one of the values stored; which one must not matter to the caller).
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class P>
+__device__ __forceinline__ int load_relaxed(P p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#else
+__device__ inline int load_relaxed(const int* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
+#endif
+
 struct FrameConst {
   double ul[3], u[3], v[3], cam[3];
   double ppw_h, ppw_v, sub;

@@ -54,6 +54,9 @@ struct SearchArgs {
   int2* cand;        // (sample, list position) candidates of the tree search, NSLOT lists of cand_cap / NSLOT
   int cand_cap;
   int nearest;       // hit policy: 1 = the hit with the smallest parameter wins (tree search only)
+  int singles;       // tree search: a ray with exactly ONE candidate gets best_pos = ~position from k_search_tree; that
+                     // pair is then decided in FP64 where the ray is shaded (k_shade_candidates), not by
+                     // k_search_exact, which only serves the rays with several candidates
   TreeDev tree;
 };
 

@@ -330,6 +330,7 @@ __device__ __forceinline__ RGBd calculate_lighting(const SceneDev& sc, const Top
 // Work tallies of a shading lane, summed per wave at the end of the kernel.
 struct ShadeTally {
   tally_t n_refl = 0, n_shadow = 0, n_hit = 0, n_tests = 0, n_elided = 0;
+  tally_t n_exact = 0;  // pairs decided with Triangle.intersections by the shading kernel itself (single candidates)
 };
 
 __device__ inline void shade_tally_flush(DevCounters* cnt, const ShadeTally& t) {
@@ -338,6 +339,7 @@ __device__ inline void shade_tally_flush(DevCounters* cnt, const ShadeTally& t) 
   wave_count(cnt, C_SHADOW, t.n_shadow);
   wave_count(cnt, C_TESTS_SECONDARY, t.n_tests);
   wave_count(cnt, C_SHADOW_ELIDED, t.n_elided);
+  wave_count(cnt, C_EXACT, t.n_exact);
 }
 
 // The intersection of sample s's primary ray (direction d) with `id` (triangle index, or -2 - object index) as the
@@ -593,13 +595,22 @@ k_shade_candidates(ShadeConst fc, SceneDev sc, TopTreeArgs ta, const f2* __restr
       const int s = c.x;
       bool deferred = false;
       double tv = 0.0;
-      const bool want = i < n && bp == c.y;  // else another triangle of this ray is listed earlier, or the pair was no hit
+      // bp < 0: the ray's only candidate (bp == ~c.y, SearchArgs::singles), still to be decided; else the candidate
+      // must be the ray's lowest hit: another triangle of the ray may be listed earlier, or the pair was no hit
+      bool want = i < n && (bp < 0 || bp == c.y);
       d3 d = rtx::mk(0.0, 0.0, 0.0);
       if (want) {
         const auto* dp = dirs + (size_t)s * 3;
         d = rtx::mk(dp[0], dp[1], dp[2]);
-        tv = rtx::tri_t(sc.planes[ti], rtx::ld3(fc.cam), d);  // k_search_exact accepted this pair
-        hit_id[s] = ti;
+        if (bp < 0) {  // Triangle.intersections for this pair, here instead of in k_search_exact
+          const rtmi_triangle& tr = sc.tris[ti];
+          d3 P;
+          want = rtx::tri_hit(rtx::ld3(tr.v[0]), rtx::ld3(tr.v[1]), rtx::ld3(tr.v[2]), sc.planes[ti], rtx::ld3(fc.cam), d, &tv, &P);
+          tl.n_exact += 1;
+        } else {
+          tv = rtx::tri_t(sc.planes[ti], rtx::ld3(fc.cam), d);  // k_search_exact accepted this pair
+        }
+        if (want) hit_id[s] = ti;
       }
       if constexpr (HAS_TOP) {
         if (want) shade_sample<true, false, NEAREST>(fc, sc, tt, s, d, ti, tv, rgb, &tl);

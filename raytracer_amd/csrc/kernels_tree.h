@@ -83,7 +83,7 @@ __device__ __forceinline__ void cand_flush(const SearchArgs* ap, const int2* sta
 // (l, j) are record (l-1, j); level-0 nodes are triangle slots, and a level-0 record is not
 // pushed but evaluated per lane: every (ray, slot) pair that passes becomes a candidate.
 template <int R>
-__global__ void __launch_bounds__(256, 6)
+__global__ void __launch_bounds__(256, R <= 4 ? 7 : 6)
 k_search_tree(const SearchArgs* __restrict__ ap, const f2* __restrict__ rec, const float* __restrict__ edge_all,
               const int* __restrict__ slot_pos, int parity) {
   __shared__ int2 stage_all[4][CAND_STAGE];
@@ -110,6 +110,10 @@ k_search_tree(const SearchArgs* __restrict__ ap, const f2* __restrict__ rec, con
   }
   unsigned n_leaf_rec = 0, n_node_rec = 0;
   int fill = 0;
+  // per ray of the lane: -1 no candidate so far, -2 several, else the list position of its only one (SearchArgs::singles)
+  int pos1[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) pos1[r] = -1;
 
   const int ltop = ap->tree.ltop, n_root = ap->tree.n_root;
   // first record of each level, in scalar registers; the select chain is scalar code
@@ -171,7 +175,10 @@ k_search_tree(const SearchArgs* __restrict__ ap, const f2* __restrict__ rec, con
             fill = 0;
             __builtin_amdgcn_wave_barrier();
           }
-          if (pass) stage[fill + __popcll(bm & ((1ull << lane) - 1ull))] = make_int2(sid[r], pos);
+          if (pass) {
+            stage[fill + __popcll(bm & ((1ull << lane) - 1ull))] = make_int2(sid[r], pos);
+            pos1[r] = pos1[r] == -1 ? pos : -2;
+          }
           fill += n;
         }
       }
@@ -214,6 +221,12 @@ k_search_tree(const SearchArgs* __restrict__ ap, const f2* __restrict__ rec, con
   }
   __builtin_amdgcn_wave_barrier();
   cand_flush(ap, stage, fill, lane, wave & (NSLOT - 1), parity);
+  if (ap->singles) {
+    int* best_pos = ap->best_pos;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (sid[r] >= 0 && pos1[r] >= 0) best_pos[sid[r]] = ~pos1[r];
+  }
 
   // work counters: (ray, triangle) cone tests at leaf level, (ray, node) tests above it
   int active = 0;
@@ -297,6 +310,39 @@ k_search_exact(const SearchArgs* __restrict__ ap, int parity) {
     }
   }
   wave_count(ap->cnt, C_EXACT, (unsigned long long)n_exact);
+}
+
+// k_search_exact when the rays with a single candidate are decided where they are shaded (SearchArgs::singles): one
+// lane per candidate, and only the candidates of rays that have several (best_pos >= 0) are examined -- one in a few
+// hundred on a closed mesh -- so the loop is kept plain.
+__global__ void __launch_bounds__(256)
+k_search_exact_multi(const SearchArgs* __restrict__ ap, int parity) {
+  DevCounters* cnt = ap->cnt;
+  unsigned int n_exact = 0;
+  if (!cnt->overflow) {
+    const int list = blockIdx.x & (NSLOT - 1), part = blockIdx.x / NSLOT, parts = gridDim.x / NSLOT;
+    const int list_cap = ap->cand_cap / NSLOT;
+    const int n = min(cnt->cand_n[parity][list][0], list_cap);
+    const auto* cand = as_global(ap->cand) + (size_t)list * list_cap;
+    auto* best_pos = as_global(ap->best_pos);
+    const d3 o = rtx::ld3(ap->cam);
+    for (int i = part * blockDim.x + threadIdx.x; i < n; i += parts * blockDim.x) {
+      const int2 c = cand[i];
+      const int s = checked(c.x, ap->n_samples, cnt, 38);
+      // the ray's only candidate (a ray with several keeps a value >= 0 whatever the atomicMin below makes of it)
+      if (load_relaxed(&best_pos[s]) < 0) continue;
+      const int pos = checked(c.y, ap->n_group, cnt, 39);
+      const int ti = checked(ap->group[pos], ap->n_tris, cnt, 40);
+      const rtmi_triangle& tr = ap->tris[ti];
+      const d3 d = rtx::mk(ap->dirs[(size_t)s * 3 + 0], ap->dirs[(size_t)s * 3 + 1], ap->dirs[(size_t)s * 3 + 2]);
+      double tv;
+      d3 P;
+      n_exact += 1;
+      if (rtx::tri_hit(rtx::ld3(tr.v[0]), rtx::ld3(tr.v[1]), rtx::ld3(tr.v[2]), ap->planes[ti], o, d, &tv, &P))
+        atomicMin((int*)&best_pos[s], pos);
+    }
+  }
+  wave_count(cnt, C_EXACT, (unsigned long long)n_exact);
 }
 
 // Nearest-hit policy, after k_search_exact: one lane per candidate; a marked candidate (a hit) whose parameter

@@ -810,6 +810,15 @@ static int search_rays_per_lane(bool tree, int nsamples) {
   if (forced) return forced;
   return tree && nsamples <= (16 << 20) ? 2 : 4;
 }
+// Rays with a single candidate are decided where they are shaded (the default), or by k_search_exact like the others
+// (RTMI_SINGLES=0, for comparison).
+static bool singles_enabled() {
+  static bool v = [] {
+    const char* e = getenv("RTMI_SINGLES");
+    return !(e && atoi(e) == 0);
+  }();
+  return v;
+}
 // Scenes with top-level triangle runs: trace the queued hits' secondary rays in one kernel and shade from the
 // recorded outcomes in another (the default), or do both in one kernel (RTMI_TRACE_THEN_SHADE=0, for comparison).
 static bool trace_then_shade() {
@@ -1119,6 +1128,9 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
     a.n_records = (int)g.n_records;
     a.cand_cap = (int)std::min<size_t>(sc->wb.cap_cand, 0x7fffffff);
     a.nearest = nearest ? 1 : 0;
+    // bounded groups under the reference's hit policy, shaded by k_shade_candidates (which decides the single
+    // candidates itself); ~position must stay apart from every position
+    a.singles = (use_tree && gi != 0 && !nearest && !ext && singles_enabled() && g.n < (1 << 30)) ? 1 : 0;
     a.tree = g.tree;
   }
   if (sc->sargs_uploaded.size() != sc->h_sargs.size() ||
@@ -1180,6 +1192,8 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
         if (nearest) {
           hipLaunchKernelGGL(k_search_exact<true>, dim3(sc->exact_grid), dim3(256), 0, st, sc->d_sargs + gi, par);
           hipLaunchKernelGGL(k_search_nearest, dim3(sc->exact_grid), dim3(256), 0, st, sc->d_sargs + gi, par);
+        } else if (sc->h_sargs[gi].singles) {
+          hipLaunchKernelGGL(k_search_exact_multi, dim3(sc->exact_grid), dim3(256), 0, st, sc->d_sargs + gi, par);
         } else {
           hipLaunchKernelGGL(k_search_exact<false>, dim3(sc->exact_grid), dim3(256), 0, st, sc->d_sargs + gi, par);
         }
