@@ -371,9 +371,10 @@ def shade_roofline(args, totals, steps, n_lights, inert):
     flops_hit += decide
     flops_hit_ref += decide
     achieved = hits * flops_hit / (ms_shade * 1e-3) / 1e12 if ms_shade > 0 else 0.0
-    # template arguments: <top-level runs, pixels only on an inert scene, nearest-hit policy>
+    # template arguments: <top-level runs, pixels only on an inert scene, nearest-hit policy>; the recorder of form T:
+    # <nearest-hit policy, secondary-ray extensions, top-level runs, bounded tree walks>
     kernel = ("k_shade_candidates<false, true, false>" if inert else
-              ("k_shade_candidates<false, false, false>" if args.form == "B" else "k_trace_top<false>"))
+              ("k_shade_candidates<false, false, false>" if args.form == "B" else "k_trace_top<false, false, true, true>"))
     # candidate entry 8 + best position 4 + direction 24 (+ the triangle 72 and its plane 32 where the pair is decided
     # here) read; hit id 4 + colour 24 written
     bytes_hit = 64 + (104 if args.form == "B" else 0)
