@@ -31,6 +31,8 @@ def main():
         "(profiles/r01_pmc_shade_kernel.json, profiles/r02_pmc_kernels.json) and the compiler's resource reports (r01/r02_kernel_resources.txt).",
         "VALU/SALU = wave-instructions per launch in millions; VALU busy = SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs);",
         "wait = SQ_WAIT_ANY / SQ_WAVE_CYCLES (share of resident wave-cycles spent waiting; round 1 did not collect the two counters).",
+        "The launches of this round also decide the rays' single candidates with Triangle.intersections (in round 1 a kernel of its",
+        "own, 0.34 ms, did that for every candidate): about 0.15 ms and 35 M VALU instructions of the figures below.",
         "",
         f"{'kernel':<62} {'VGPRs':>5} {'scratch':>7} {'waves':>5} {'ms':>8} {'VALU M':>10} {'SALU M':>10} {'VALU busy':>9} {'wait':>6}",
         row("round 1: k_shade_candidates<false> (all hits, rays traced)", resources(r1, "k_shade_candidates<false>"), 1.54, a, waits=False),
