@@ -1,8 +1,10 @@
 /*
  * rt_oracle.c -- CPU FP64 restatement of nealsid/RayTracer's render core.
  *
- * TEST INFRASTRUCTURE ONLY (see rt_oracle.h).  Parity unpinned by the reference's own
- * artefacts (it has none); pinned by hand-derived known-answer vectors.
+ * TEST INFRASTRUCTURE ONLY (see rt_oracle.h).  Pinned to the reference's one artefact, the
+ * rendered view in its screenshot, for what that can resolve (sphere scenes, 1/255); parity
+ * unpinned by the reference beyond that: hand-derived known-answer vectors and a second
+ * restatement hold the rest (rt_oracle.h says which parts).
  *
  * Every function follows the reference's arithmetic operation by operation: same operand
  * order, true divisions where the reference divides, no fused multiply-add (build with

@@ -6,9 +6,16 @@
  * (librtmi.so) never does.
  *
  * Parity pin status: the reference ships no tests, golden vectors or fixtures and cannot be
- * compiled here (Swift/AppKit, no Swift toolchain), so this restatement is pinned by
- * known-answer vectors derived by hand from the reference source (tests/test_oracle_kat.py)
- * and by nothing else: "parity unpinned" by the reference's own artefacts.
+ * compiled here (Swift/AppKit, no Swift toolchain).  The one output of the reference that exists --
+ * the rendered view inside its RayTraceExample.png, two spheres and three lights -- is compared pixel
+ * by pixel with this restatement's frame of the same scene (tests/test_reference_screenshot.py); that
+ * pins the camera model, the sphere test, list order, calculateLighting for sphere hits, clamping and
+ * the 8-bit quantisation to what 1/255 can resolve.  Triangles, bounding spheres, supersampling,
+ * lights used as objects and everything below 1/255 rest on known-answer vectors derived by hand
+ * from the reference source (tests/test_oracle_kat.py) and on a second, separately written
+ * restatement (oracle/swift_walkthrough.py): for those, "parity unpinned" by the reference's own
+ * artefacts.  The extension switches (RTMI_HIT_NEAREST, RTMI_FLAG_SHADOW_*, ..._ENTER_BOUNDED) have
+ * no counterpart in the reference at all; with them off this file states the reference.
  *
  * Scene/camera/parameter structs are the plain C structs of include/rtmi.h (types only).
  */
