@@ -42,6 +42,10 @@ for _step in (0, 1, 2, 3, 4, 5, 6, 7, 16, 32, 48):
 # form T (triangles listed at top level, so reflection and shadow rays do triangle work) at a size the
 # oracle finishes: every secondary ray scans the list
 FRAMES["T_640x360"] = (640, 360, 0.5, 3, 3, "T", "mesh")
+# the secondary-ray extensions (not the reference's behaviour): the C2 frame size with three lights, a material on the
+# mesh's triangles (so that its shadows and mirror images show) and all three flags
+EXTENSION_FRAMES = {"C2_extensions": dict(flags=14, triangle_material=0)}
+FRAMES["C2_extensions"] = (1024, 1024, 0.5, 4, 3, "B", "mesh")
 
 
 def camera_kw(cam):
@@ -77,11 +81,14 @@ def main():
             continue
         W, H, sub, level, n_lights, form, cam = FRAMES[name]
         data = scenes.mesh_scene(level, form, n_lights, bounding_sphere=oracle.bounding_sphere)
-        params = scenes.make_params(W, H, sub)
+        ext = EXTENSION_FRAMES.get(name, {})
+        if "triangle_material" in ext:
+            data.triangles["material"] = ext["triangle_material"]
+        params = scenes.make_params(W, H, sub, flags=ext.get("flags", 0))
         t0 = time.time()
         rgba, hit, cnt = oracle.render(data, scenes.make_camera(**camera_kw(cam)), params, threads=args.threads)
         rec = {"width": W, "height": H, "subdivision": sub, "mesh_level": level, "lights": n_lights, "form": form,
-               "camera": cam, "band_rows": BAND, "scene_sha256": scene_digest(data),
+               "camera": cam, "band_rows": BAND, "scene_sha256": scene_digest(data), **ext,
                "counters": {k: int(cnt[k]) for k in ("samples", "rays_reflection", "rays_shadow", "tri_tests",
                                                      "sphere_tests", "primary_hits")},
                "oracle_seconds": round(time.time() - t0, 1), "oracle_threads": args.threads}

@@ -26,6 +26,8 @@ COUNTERS = ("samples", "rays_reflection", "rays_shadow", "sphere_tests", "primar
 
 def scene_for(rec, rt):
     data = scenes.mesh_scene(rec["mesh_level"], rec["form"], rec["lights"], bounding_sphere=rt.bounding_sphere)
+    if "triangle_material" in rec:
+        data.triangles["material"] = rec["triangle_material"]
     h = hashlib.sha256()
     for a in (data.lights, data.materials, data.objects, data.triangles):
         h.update(np.ascontiguousarray(a).tobytes())
@@ -61,13 +63,14 @@ def buffers(rec, rt):
     return rgba, hit
 
 
-@pytest.mark.parametrize("name", [n for n in ("C2", "C3", "C4", "T_640x360") if n in GOLDEN])
+@pytest.mark.parametrize("name", [n for n in ("C2", "C3", "C4", "T_640x360", "C2_extensions") if n in GOLDEN])
 def test_whole_frame_equals_the_oracles(rt, name):
     rec = GOLDEN[name]
     sc = rt.Scene(scene_for(rec, rt))
     cam = camera_for(rec)
     for search in (_abi.RTMI_SEARCH_CONE_TREE, _abi.RTMI_SEARCH_LIST_SCAN):
-        p = scenes.make_params(rec["width"], rec["height"], rec["subdivision"], search=search)
+        # (C2_extensions: the secondary-ray extension flags the digest was made with)
+        p = scenes.make_params(rec["width"], rec["height"], rec["subdivision"], search=search, flags=rec.get("flags", 0))
         rgba, hit = buffers(rec, rt)
         torch.cuda.synchronize()
         cnt = sc.render_device(cam, p, rgba.data_ptr(), hit.data_ptr())
