@@ -860,7 +860,10 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
   constexpr int ENTER_FLAGS = RTMI_FLAG_SHADOWS_ENTER_BOUNDED | RTMI_FLAG_REFLECTIONS_ENTER_BOUNDED;
   if (p->flags & ~(RTMI_FLAG_NO_RAY_STATISTICS | EXT_FLAGS)) return RTMI_ERR_INVALID_ARGUMENT;
   // the secondary-ray extensions: every hit is shaded from the shade queue
-  const int ext_flags = p->flags & EXT_FLAGS;
+  int ext_flags = p->flags & EXT_FLAGS;
+  // the distance limit alone, in a scene whose list holds nothing that can block a light (bounding spheres only, what
+  // loadObjFile builds): the frame is the reference's
+  if (ext_flags == RTMI_FLAG_SHADOW_MAX_DISTANCE && sc->groups[0].n == 0 && sc->n_plain_shadeable == 0) ext_flags = 0;
   const bool ext = ext_flags != 0;
   if (ext && sc->no_alloc) {
     g_last_error = "rtmi_render_device_noalloc: the secondary-ray extension flags are not supported";
