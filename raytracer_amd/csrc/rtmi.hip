@@ -1267,13 +1267,20 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
                      ext_args, (const f2*)sc->d_brec, (const float*)sc->d_bgst2, (const int*)sc->d_bslot_pos,               \
                      (const int*)sc->d_bmembers, (const int*)sc->d_bowner, sc->wb.dirs, sc->wb.tval, sc->wb.q_shade,         \
                      &sc->wb.cnt->q_shade, sc->wb.hit_id, sc->wb.rgb, sc->wb.cnt)
-      if (ext && !nearest && trace_then_shade() && sc->dev.n_lights <= TRACE_MAX_LIGHTS) {
+      if (ext && trace_then_shade() && sc->dev.n_lights <= TRACE_MAX_LIGHTS) {
         // the recorder without the walks that cannot happen on this scene and frame
         const bool enter = (ext_flags & ENTER_FLAGS) != 0;
-        if (has_top_runs && enter) RTMI_LAUNCH_TRACE_REPLAY(false, true, true, true);
-        else if (has_top_runs) RTMI_LAUNCH_TRACE_REPLAY(false, true, true, false);
-        else if (enter) RTMI_LAUNCH_TRACE_REPLAY(false, true, false, true);
-        else RTMI_LAUNCH_TRACE_REPLAY(false, true, false, false);
+        if (nearest) {
+          if (has_top_runs && enter) RTMI_LAUNCH_TRACE_REPLAY(true, true, true, true);
+          else if (has_top_runs) RTMI_LAUNCH_TRACE_REPLAY(true, true, true, false);
+          else if (enter) RTMI_LAUNCH_TRACE_REPLAY(true, true, false, true);
+          else RTMI_LAUNCH_TRACE_REPLAY(true, true, false, false);
+        } else {
+          if (has_top_runs && enter) RTMI_LAUNCH_TRACE_REPLAY(false, true, true, true);
+          else if (has_top_runs) RTMI_LAUNCH_TRACE_REPLAY(false, true, true, false);
+          else if (enter) RTMI_LAUNCH_TRACE_REPLAY(false, true, false, true);
+          else RTMI_LAUNCH_TRACE_REPLAY(false, true, false, false);
+        }
       } else if (ext) {
         if (nearest) RTMI_LAUNCH_SHADE_EXT(true);
         else RTMI_LAUNCH_SHADE_EXT(false);
