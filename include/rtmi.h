@@ -105,7 +105,8 @@ typedef enum {
                               intersections[0] (RayTracingFunctions.swift:83, :93, :216) the intersection with the
                               smallest parameter is taken, the first in list order among equal parameters; shadow rays
                               (:236-243, "is anything hit") are unaffected.  Cone-tree search only
-                              (RTMI_SEARCH_LIST_SCAN: RTMI_ERR_UNSUPPORTED). */
+                              (RTMI_SEARCH_LIST_SCAN: RTMI_ERR_UNSUPPORTED).  A frame with more candidate pairs than
+                              the search's lists hold is rendered again with longer lists. */
 } rtmi_hit_policy;
 
 /* How the triangles of a group are searched for a primary ray.  Both give the same hits. */
@@ -168,7 +169,9 @@ typedef struct {
  * With any of the three every hit of a frame is shaded from a queue after the search, all its secondary rays traced
  * (RTMI_FLAG_NO_RAY_STATISTICS has no effect), and rtmi_render_device_noalloc refuses the frame
  * (RTMI_ERR_UNSUPPORTED): the first frame that asks for one of the ..._ENTER_BOUNDED flags builds a bounding-sphere
- * tree over the children of all bounding spheres and keeps it with the scene. */
+ * tree over the children of all bounding spheres and keeps it with the scene; that one call -- rtmi_render_begin
+ * included -- waits for the scene's stream, copies the triangles back to the host and builds the tree there before it
+ * enqueues anything (a failure on the way leaves the scene as it was, and a later frame tries again). */
 #define RTMI_FLAG_SHADOW_MAX_DISTANCE 2
 #define RTMI_FLAG_SHADOWS_ENTER_BOUNDED 4
 #define RTMI_FLAG_REFLECTIONS_ENTER_BOUNDED 8
@@ -237,7 +240,10 @@ int32_t rtmi_scene_create(const rtmi_scene_desc* desc, int32_t device, rtmi_scen
 
 void rtmi_scene_destroy(rtmi_scene* scene);
 
-/* raytraceWorld (RayTracingFunctions.swift:145-180) into caller-owned HOST buffers.
+/* Every render call below: when the status is not RTMI_OK the contents of the output buffers are undefined (kernels
+ * of the frame may have written part of it), except that rtmi_render leaves the caller's host buffers untouched.
+ *
+ * raytraceWorld (RayTracingFunctions.swift:145-180) into caller-owned HOST buffers.
  *   rgba_out    4*width*height bytes, row-major RGBA8, bytesPerRow = 4*width
  *               (RayTracingFunctions.swift:67,106-111); only rendered pixels are written.
  *   hit_id_out  optional; width*height*spp int32, index (y*width + x)*spp + k with k in
@@ -282,8 +288,10 @@ int32_t rtmi_render_end(rtmi_scene* scene, rtmi_counters* counters);
  * as (8x8 pixel blocks the window touches) x 64 x samples per pixel, and
  * (width + height) x sub-samples per axis <= 16,384; a larger frame is refused with
  * RTMI_ERR_UNSUPPORTED and rtmi_last_error() says which limit.  All calls on one GPU share that
- * GPU's array: calls that overlap in time on one GPU (from several scenes or threads) race and
- * must be serialised by the caller.  Results are identical to rtmi_render_device's. */
+ * GPU's array, which keeps the last call's contents; calls of one process that overlap in time on one GPU
+ * (from several scenes or threads) are made to take turns by a per-device lock inside the library (the
+ * call is synchronous, so the lock costs nothing).  Calls from SEVERAL PROCESSES cannot overlap: each
+ * process holds its own copy of the array.  Results are identical to rtmi_render_device's. */
 int32_t rtmi_render_device_noalloc(rtmi_scene* scene, const rtmi_camera* camera,
                                    const rtmi_params* params, void* rgba_dev, void* hit_id_dev,
                                    rtmi_counters* counters);

@@ -97,6 +97,22 @@ struct WalkExt {
                             // known to intersect it (RTMI_FLAG_REFLECTIONS_ENTER_BOUNDED)
 };
 
+// PRECONDITION of the three walks below (top_tree_trace, top_tree_trace_nearest, and shadow_blocked_ext /
+// reflection_enters_bounded through them): |d| = 1 to within FP64 rounding.  The half-line test takes A = d.(c - o) as a
+// distance along the ray and the cone-of-normals test compares a.d with sin(theta): a shorter d would reject spheres the
+// ray passes, a longer one would pass over front-facing nodes.  Every caller passes the output of rtx::normalize or
+// the reflection of one unit vector about another (RTF:209-211, :227), which is what the reference traces with too:
+// its Sphere.intersections (REN:251-253) assumes the same.  The CPU build of the kernels checks it.
+__device__ inline void walk_wants_unit_direction(d3 d) {
+#if !defined(__HIPCC__)  // the CPU build of the kernels (tests/emu)
+  const double l2 = d.x * d.x + d.y * d.y + d.z * d.z;
+  if (l2 == l2 && !(fabs(l2 - 1.0) < 1e-9)) {  // (a NaN direction hits nothing either way)
+    fprintf(stderr, "secondary-ray walk called with |d|^2 = %.17g\n", l2);
+    abort();
+  }
+#endif
+}
+
 // A general-origin ray (reflection or shadow ray) against ALL top-level triangles: the ordinal of
 // the hit that comes first in list order (any_only: of some hit), or -1.  The lanes that call this
 // together walk the tree together, like k_search_tree: a record of eight bounding spheres is
@@ -108,6 +124,7 @@ struct WalkExt {
 template <bool EXT = false>
 __device__ inline int top_tree_trace(const SceneDev& sc, const TopTreeRef& T, d3 o, d3 d, bool any_only, double* t_out,
                                      d3* P_out, tally_t* n_tests, const WalkExt* WX = nullptr) {
+  walk_wants_unit_direction(d);
   const double c0x = EXT ? WX->c0[0] : sc.c0[0], c0y = EXT ? WX->c0[1] : sc.c0[1], c0z = EXT ? WX->c0[2] : sc.c0[2];
   const long long n_members = EXT ? WX->n_members : sc.n_top_tris;
   const int* members = EXT ? WX->members : sc.top_group;
@@ -354,6 +371,7 @@ __device__ inline bool trace_top_secondary(const SceneDev& sc, const TopTreeRef&
 template <bool EXT = false>
 __device__ inline int top_tree_trace_nearest(const SceneDev& sc, const TopTreeRef& T, d3 o, d3 d, bool any_only, double* t_out,
                                      d3* P_out, tally_t* n_tests, const WalkExt* WX = nullptr) {
+  walk_wants_unit_direction(d);
   const bool nearest = !any_only;  // the hit with the smallest parameter instead of the lowest ordinal
   double best_t = 0.0;
   const double c0x = EXT ? WX->c0[0] : sc.c0[0], c0y = EXT ? WX->c0[1] : sc.c0[1], c0z = EXT ? WX->c0[2] : sc.c0[2];

@@ -146,6 +146,8 @@ static __device__ __align__(256) unsigned char scratch[SCRATCH_BYTES];
 
 static std::mutex g_scratch_mu;
 static unsigned char* g_scratch_ptr[MAX_DEVICES];
+// held for the whole of a rtmi_render_device_noalloc call: the calls of one device share its array, so they take turns
+static std::mutex g_scratch_busy[MAX_DEVICES];
 
 constexpr size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 constexpr size_t scratch_bytes_needed() {
@@ -761,40 +763,57 @@ static int32_t ensure_bounded_tree(rtmi_scene* sc) {
   }
   ExtArgs args{};
   if (!members.empty()) {
-    HIP_TRY(hipStreamSynchronize(sc->stream));
-    std::vector<rtmi_triangle> tris((size_t)sc->n_tris);
-    HIP_TRY(hipMemcpy(tris.data(), sc->d_tris, sizeof(rtmi_triangle) * tris.size(), hipMemcpyDeviceToHost));
-    double c0[3] = {0.0, 0.0, 0.0}, r_o1 = 0.0;
-    general_frame(tris.data(), sc->n_tris, sc->objects.data(), (int64_t)sc->objects.size(), sc->h_lights.data(), members, c0, &r_o1);
-    TreeHost th;
-    tree_build_host(tris.data(), members, &th);
-    auto upload = [&](void** dst, const void* src, size_t bytes) -> int32_t {
-      HIP_TRY(hipMalloc(dst, bytes));
-      HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+    // the five device arrays are built into locals and handed to the scene only when all of them exist: a failure
+    // half-way (out of memory) frees what it made and leaves the scene as it was
+    void* made[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // members, owner, slot_pos, gst2, records
+    auto build = [&]() -> int32_t {
+      HIP_TRY(hipStreamSynchronize(sc->stream));
+      std::vector<rtmi_triangle> tris((size_t)sc->n_tris);
+      HIP_TRY(hipMemcpy(tris.data(), sc->d_tris, sizeof(rtmi_triangle) * tris.size(), hipMemcpyDeviceToHost));
+      double c0[3] = {0.0, 0.0, 0.0}, r_o1 = 0.0;
+      general_frame(tris.data(), sc->n_tris, sc->objects.data(), (int64_t)sc->objects.size(), sc->h_lights.data(), members, c0, &r_o1);
+      TreeHost th;
+      tree_build_host(tris.data(), members, &th);
+      auto upload = [&](void** dst, const void* src, size_t bytes) -> int32_t {
+        HIP_TRY(hipMalloc(dst, bytes));
+        HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+        return RTMI_OK;
+      };
+      int32_t rc;
+      const size_t nm = members.size();
+      if ((rc = upload(&made[0], members.data(), sizeof(int) * nm))) return rc;
+      if ((rc = upload(&made[1], owner.data(), sizeof(int) * nm))) return rc;
+      if ((rc = upload(&made[2], th.slot_pos.data(), sizeof(int) * th.slot_pos.size()))) return rc;
+      HIP_TRY(hipMalloc(&made[3], sizeof(float) * GST2_FLOATS * nm));
+      hipLaunchKernelGGL(k_pack_general, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, sc->stream, sc->d_tris,
+                         (const int*)made[0], (int)nm, rtx::mk(c0[0], c0[1], c0[2]), r_o1, (float*)made[3]);
+      HIP_TRY(hipGetLastError());
+      std::vector<float> trec;
+      unsigned cone_levels = 0;
+      tree_sphere_records(tris.data(), th, c0, r_o1, &trec, &cone_levels);
+      if ((rc = upload(&made[4], trec.data(), sizeof(float) * trec.size()))) return rc;
+      args.tree.cone_levels = normal_cones_enabled() ? (int)cone_levels : 0;
+      args.tree.ltop = th.dev.ltop;
+      args.tree.n_root = th.dev.n_root;
+      args.tree.n_slots = th.dev.n_slots;
+      args.tree.n_records = (int)th.n_records;
+      for (int l = 0; l < TREE_MAX_LEVELS; ++l) args.tree.off[l] = th.dev.rec_off[l];
+      args.n_bounded = (long long)nm;
+      for (int a = 0; a < 3; ++a) args.c0[a] = c0[a];
+      HIP_TRY(hipStreamSynchronize(sc->stream));
       return RTMI_OK;
     };
-    int32_t rc;
-    const size_t nm = members.size();
-    if ((rc = upload((void**)&sc->d_bmembers, members.data(), sizeof(int) * nm))) return rc;
-    if ((rc = upload((void**)&sc->d_bowner, owner.data(), sizeof(int) * nm))) return rc;
-    if ((rc = upload((void**)&sc->d_bslot_pos, th.slot_pos.data(), sizeof(int) * th.slot_pos.size()))) return rc;
-    HIP_TRY(hipMalloc(&sc->d_bgst2, sizeof(float) * GST2_FLOATS * nm));
-    hipLaunchKernelGGL(k_pack_general, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, sc->stream, sc->d_tris,
-                       sc->d_bmembers, (int)nm, rtx::mk(c0[0], c0[1], c0[2]), r_o1, sc->d_bgst2);
-    HIP_TRY(hipGetLastError());
-    std::vector<float> trec;
-    unsigned cone_levels = 0;
-    tree_sphere_records(tris.data(), th, c0, r_o1, &trec, &cone_levels);
-    if ((rc = upload((void**)&sc->d_brec, trec.data(), sizeof(float) * trec.size()))) return rc;
-    args.tree.cone_levels = normal_cones_enabled() ? (int)cone_levels : 0;
-    args.tree.ltop = th.dev.ltop;
-    args.tree.n_root = th.dev.n_root;
-    args.tree.n_slots = th.dev.n_slots;
-    args.tree.n_records = (int)th.n_records;
-    for (int l = 0; l < TREE_MAX_LEVELS; ++l) args.tree.off[l] = th.dev.rec_off[l];
-    args.n_bounded = (long long)nm;
-    for (int a = 0; a < 3; ++a) args.c0[a] = c0[a];
-    HIP_TRY(hipStreamSynchronize(sc->stream));
+    const int32_t rc = guarded(build);
+    if (rc != RTMI_OK) {
+      (void)hipStreamSynchronize(sc->stream);  // k_pack_general may still be writing made[3]
+      for (void* p : made) (void)hipFree(p);
+      return rc;
+    }
+    sc->d_bmembers = (int*)made[0];
+    sc->d_bowner = (int*)made[1];
+    sc->d_bslot_pos = (int*)made[2];
+    sc->d_bgst2 = (float*)made[3];
+    sc->d_brec = (float*)made[4];
   }
   sc->bounded_args = args;
   sc->bounded_tree_built = true;
@@ -1339,9 +1358,29 @@ static int32_t render_finish(rtmi_scene* sc, rtmi_counters* counters) {
     // stacks of overlapping triangles): the frame is rendered again with the list scan, which
     // needs no such list and gives the same image.
     if (sc->pend_params.hit_policy == RTMI_HIT_NEAREST) {
-      g_last_error = "the frame has more candidate pairs than the lists hold, and RTMI_HIT_NEAREST has no list-scan fallback";
-      return RTMI_ERR_UNSUPPORTED;
-    }
+      // no list scan under this policy: the lists are made four times as long and the frame is rendered again with the
+      // tree, until they hold it (the static array of rtmi_render_device_noalloc cannot grow: that call fails, and
+      // its output buffers hold an incomplete frame)
+      const rtmi_camera cam2 = sc->pend_cam;
+      const rtmi_params p2 = sc->pend_params;
+      for (int attempt = 0; sc->h_cnt->overflow; ++attempt) {
+        if (sc->no_alloc || attempt == 8 || sc->wb.cap_cand > ((size_t)1 << 31)) {
+          g_last_error = "the frame has more candidate pairs than the lists hold, and RTMI_HIT_NEAREST has no list-scan fallback; "
+                         "the output buffers hold an incomplete frame";
+          return RTMI_ERR_UNSUPPORTED;
+        }
+        const size_t grown = std::max<size_t>(sc->wb.cap_cand * 4, (size_t)NSLOT * 1024);
+        (void)hipFree(sc->wb.cand);
+        sc->wb.cand = nullptr;
+        sc->wb.cap_cand = 0;
+        HIP_TRY(hipMalloc(&sc->wb.cand, sizeof(int2) * grown));
+        sc->wb.cap_cand = grown;
+        int32_t rc = render_enqueue(sc, &cam2, &p2, sc->pend_rgba, sc->pend_hit);
+        if (rc != RTMI_OK) return rc;
+        sc->pending = false;
+        HIP_TRY(hipStreamSynchronize(sc->stream));
+      }
+    } else {
     rtmi_params p2 = sc->pend_params;
     p2.search = RTMI_SEARCH_LIST_SCAN;
     const rtmi_camera cam2 = sc->pend_cam;
@@ -1350,6 +1389,7 @@ static int32_t render_finish(rtmi_scene* sc, rtmi_counters* counters) {
     sc->pending = false;
     HIP_TRY(hipStreamSynchronize(sc->stream));
     sc->pend_params.search = RTMI_SEARCH_CONE_TREE;
+    }
   }
   const DevCounters& hc = *sc->h_cnt;
   if (hc.bug) {
@@ -1440,6 +1480,7 @@ static int32_t render_noalloc_impl(rtmi_scene* sc, const rtmi_camera* cam, const
     g_last_error = "rtmi_render_device_noalloc: no static work array on device " + std::to_string(sc->device);
     return RTMI_ERR_UNSUPPORTED;
   }
+  std::lock_guard<std::mutex> turn(g_scratch_busy[sc->device]);
   WorkBufs own = sc->wb;
   sc->wb = carve_scratch(base);
   sc->no_alloc = true;

@@ -39,23 +39,37 @@ RT_HD d3 divs(d3 a, double s) { return mk(a.x / s, a.y / s, a.z / s); }  // vect
 RT_HD double dp(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 // lenSquared, UTL:38-40
 RT_HD double len_squared(d3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
-// normalize, UTL:27-30: three true divisions by the square root.  The three quotients share one division:
-// with r = 1/length correctly rounded (an IEEE division), q = x*r and e = fma(-q, length, x) -- the exact
-// residual x - q*length -- the value fma(e, r, q) is the correctly rounded quotient x/length (Markstein's
-// division step: r is the correctly rounded reciprocal and q is within an ulp of the quotient).  That holds
+// normalize, UTL:27-30: three true divisions by the square root.  The three quotients share one division.
+// With r = RN(1/length) (an IEEE division, so within half an ulp of 1/length) a quotient x/length is built in
+// three steps:
+//   q0 = RN(x*r)                        relative error below 2^-52, i.e. up to about two ulps when the quotient's
+//                                       significand is close to 2 -- not yet a faithful rounding;
+//   q1 = RN(q0 + RN(x - q0*length)*r)   the residual is computed by one fma with a relative error of at most 2^-53,
+//                                       so q0 + residual*r lies within 2^-50 ulp of x/length before its rounding:
+//                                       q1 is within 0.5 + 2^-50 ulp of x/length, a faithful rounding;
+//   q2 = RN(q1 + (x - q1*length)*r)     Markstein's correction step (Markstein 1990; Muller et al., Handbook of
+//                                       Floating-Point Arithmetic, "correctly rounded division"): for a faithful q1
+//                                       the residual x - q1*length is exactly representable (the fma returns it
+//                                       without rounding), and with r within half an ulp of 1/length the result is
+//                                       RN(x/length), the bits of the plain division, in every rounding case.
+// (Stopping at q1 -- as this function did at first -- gives the same bits unless x/length lies within 2^-50 ulp of the
+// midpoint of two doubles, which random testing cannot reach; q2 rests on the theorem instead.)  All of it holds
 // while nothing under- or overflows on the way, which the guard ensures: length and every component within
-// 2^-500 .. 2^500 in magnitude (a zero component takes the plain divisions too, they keep its sign).  The
-// result is the same bits as three divisions; on gfx950 it costs one division and nine multiply-adds
-// instead of three divisions (an IEEE division is a 13-instruction sequence there).
+// 2^-500 .. 2^500 in magnitude (a zero component takes the plain divisions too, they keep its sign).  On gfx950
+// this is one division and fifteen multiply-adds instead of three divisions (an IEEE division is a 13-instruction
+// sequence there).
+RT_HD double shared_quotient(double x, double length, double r) {
+  const double q0 = x * r;
+  const double q1 = __builtin_fma(__builtin_fma(-q0, length, x), r, q0);
+  return __builtin_fma(__builtin_fma(-q1, length, x), r, q1);
+}
 RT_HD d3 normalize(d3 a) {
   const double length = sqrt(dp(a, a));
   const double lo = 3.054936363499605e-151, hi = 3.273390607896142e+150;  // 2^-500, 2^500
   const double ax = fabs(a.x), ay = fabs(a.y), az = fabs(a.z);
   if (length >= lo && length <= hi && ax >= lo && ay >= lo && az >= lo) {  // components cannot exceed length by more than an ulp
     const double r = 1.0 / length;
-    const double qx = a.x * r, qy = a.y * r, qz = a.z * r;
-    return mk(__builtin_fma(__builtin_fma(-qx, length, a.x), r, qx), __builtin_fma(__builtin_fma(-qy, length, a.y), r, qy),
-              __builtin_fma(__builtin_fma(-qz, length, a.z), r, qz));
+    return mk(shared_quotient(a.x, length, r), shared_quotient(a.y, length, r), shared_quotient(a.z, length, r));
   }
   return mk(a.x / length, a.y / length, a.z / length);
 }
@@ -71,9 +85,7 @@ RT_HD void normalize_n(const d3 (&a)[N], d3 (&out)[N]) {
   for (int k = 0; k < N; ++k) length[k] = sqrt(dp(a[k], a[k]));
   for (int k = 0; k < N; ++k) r[k] = 1.0 / length[k];
   for (int k = 0; k < N; ++k) {
-    const double qx = a[k].x * r[k], qy = a[k].y * r[k], qz = a[k].z * r[k];
-    out[k] = mk(__builtin_fma(__builtin_fma(-qx, length[k], a[k].x), r[k], qx), __builtin_fma(__builtin_fma(-qy, length[k], a[k].y), r[k], qy),
-                __builtin_fma(__builtin_fma(-qz, length[k], a[k].z), r[k], qz));
+    out[k] = mk(shared_quotient(a[k].x, length[k], r[k]), shared_quotient(a[k].y, length[k], r[k]), shared_quotient(a[k].z, length[k], r[k]));
     ok = ok && length[k] >= lo && length[k] <= hi && fabs(a[k].x) >= lo && fabs(a[k].y) >= lo && fabs(a[k].z) >= lo;
   }
   if (!ok) {

@@ -3,7 +3,8 @@
 //   normalize_check <millions of vectors> [seed]
 // Vectors are drawn from several families that stress the rounding of a quotient: random mantissas with
 // exponents spread over a wide or a narrow range, mantissas of all ones or all zeros (powers of two), components
-// that are tiny fractions of the length, axis-aligned and near-axis vectors, and vectors far outside the guard's
+// that are tiny fractions of the length, axis-aligned and near-axis vectors (quotients just below 1, lengths whose
+// significand is all ones: the cases a shared-division scheme is most likely to round wrongly), and vectors far outside the guard's
 // range (which must take the plain divisions and still agree).  rtx::normalize3 (three at once) is held to
 // rtx::normalize on every run of three consecutive vectors, which mixes guarded and unguarded ones.
 #include <cmath>
@@ -33,6 +34,8 @@ static double draw(uint64_t& s, int family) {
     case 4: mant = 0xFFFFFFFFFFFFFull - (r & 7); e = (int)((r >> 52) % 5) - 2; break; // just below a power of two
     case 5: mant = r & 15; e = (int)((r >> 52) % 5) - 2; break;                       // just above a power of two
     case 6: e = (int)((r >> 52) % 3) - 60 * (int)((r >> 60) & 1); break;              // one component tiny next to the others
+    case 8: e = -24 - (int)((r >> 52) % 8); break;  // with a family-0 first component: a quotient just below 1 (significand near 2)
+    case 9: e = -60; break;                          // with an all-ones first component: the length is that component, all ones
     default: e = (int)((r >> 52) % 3); break;
   }
   const uint64_t sign = (r >> 63) << 63;
@@ -49,8 +52,12 @@ int main(int argc, char** argv) {
     uint64_t s = (seed + 0x9E3779B97F4A7C15ull * (uint64_t)(chunk + 1)) | 1;
     rtx::d3 recent[3];  // the last three vectors: normalize3 must agree with normalize on every triple
     for (int k = 0; k < 1000; ++k) {
-      const int family = (int)(next(s) % 8);
+      const int family = (int)(next(s) % 10);
       rtx::d3 v = rtx::mk(draw(s, family), draw(s, family), draw(s, (next(s) & 3) ? family : 0));
+      // directed cases: quotients whose significand is close to 2 (the first approximation of such a quotient may be two
+      // ulps off), and a length whose significand is all ones
+      if (family == 8) { v.x = draw(s, 0); v.y *= v.x; v.z = draw(s, 8) * v.x; }
+      if (family == 9) { v.x = draw(s, 2); v.z = draw(s, 9) * v.x; }
       if ((next(s) & 31) == 0) v.y = 0.0;          // axis-aligned now and then
       if ((next(s) & 63) == 0) v.z = -0.0;
       const double length = sqrt(rtx::dp(v, v));

@@ -188,6 +188,17 @@ def test_emulated_candidate_list_overflow(emu, oracle_mod, tmp_path, capacity):
             assert cnt.node_tests == 0 and cnt.tri_tests_primary_kernel > 0
 
 
+def test_emulated_candidate_list_overflow_under_the_nearest_hit_policy(emu, oracle_mod, tmp_path):
+    """The nearest-hit policy has no list scan to fall back on: the lists are made longer and the frame is rendered
+    again with the tree until they hold it (two frames, so the second starts from the grown lists)."""
+    cam = scenes.make_camera((0, 0, 4), (0, 0, -1), 10.0)
+    data_b = scenes.mesh_scene(level=2, form="B", n_lights=3, bounding_sphere=oracle_mod.bounding_sphere)
+    p = scenes.make_params(36, 30, 0.5, hit_policy=_abi.RTMI_HIT_NEAREST)
+    out = run_case(emu, oracle_mod, tmp_path / "B", data_b, [cam, cam], p, searches=("tree",), env={"RTMI_CAND_CAPACITY": "64"})
+    for _, _, cnt in out["tree"]:
+        assert cnt.node_tests > 0 and cnt.tri_candidates > 64
+
+
 def test_emulated_random_scenes(emu, oracle_mod):
     """A few cases of the scene fuzzer (tests/emu_fuzz.py); long runs of it are done by hand."""
     import emu_fuzz

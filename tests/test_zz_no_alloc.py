@@ -35,7 +35,8 @@ FRAMES = [(160, 90, 0.5), (96, 72, 1.0), (120, 60, 0.5)]
 
 
 @pytest.mark.gpu
-def test_noalloc_matches_render_device_on_consecutive_calls(rt):
+def test_noalloc_matches_render_device_on_consecutive_calls(rt, oracle_mod):
+    import copy
     L = rt.lib()
     assert L.rtmi_noalloc_max_samples() == 65536
     for data in (mixed_scene(rt.bounding_sphere), scenes.mesh_scene(3, "B", 3, bounding_sphere=rt.bounding_sphere)):
@@ -59,6 +60,14 @@ def test_noalloc_matches_render_device_on_consecutive_calls(rt):
                 assert (b[1] != -77).any() and (b[1] >= 0).any()
                 for k in PARITY_COUNTERS:
                     assert a[2][k] == b[2][k], (W, H, sub, search, k)
+                # and against the oracle itself: hit ids and RGBA8 of the rendered (W-1) x (H-1) pixels, the rest untouched
+                o_rgba, o_hit, o_cnt = oracle_mod.render(data, cam, copy.copy(p), threads=8)
+                m = np.zeros((H, W), bool)
+                m[:H - 1, :W - 1] = True
+                assert (a[1][m] == o_hit[m]).all(), f"{W}x{H} sub {sub} search {search}: hit ids differ from the oracle's"
+                assert (a[0][m] == o_rgba[m]).all(), f"{W}x{H} sub {sub} search {search}: RGBA8 differs from the oracle's"
+                assert (a[0][~m] == 0x5A).all() and (a[1][~m] == -77).all()
+                assert a[2]["primary_hits"] == o_cnt["primary_hits"] and a[2]["rays_shadow"] == o_cnt["rays_shadow"]
         # beyond the limits: refused with a message, nothing rendered, and the scene still works afterwards
         big = scenes.make_params(400, 300, 0.5)
         rgba = torch.zeros((300, 400, 4), dtype=torch.uint8, device="cuda")
@@ -82,6 +91,72 @@ def test_noalloc_matches_render_device_on_consecutive_calls(rt):
         sc.render_device(cam, big, torch.zeros((300, 400, 4), dtype=torch.uint8, device="cuda").data_ptr())
         sc.close()
         ref_sc.close()
+
+
+@pytest.mark.gpu
+def test_noalloc_allocates_no_device_memory(rt):
+    """hipMemGetInfo's free byte count stays where it was over 120 calls that alternate between two frame sizes and
+    two searches (everything the caller needs -- output buffers -- exists before the first reading)."""
+    data = mixed_scene(rt.bounding_sphere)
+    sc = rt.Scene(data)
+    cam = scenes.make_camera(**CAM)
+    frames = []
+    for (W, H, sub) in FRAMES[:2]:
+        spp = rt.samples_per_pixel(sub)
+        frames.append((W, H, sub, torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda"),
+                       torch.zeros((H, W, spp), dtype=torch.int32, device="cuda")))
+    params = [scenes.make_params(W, H, sub, search=search) for (W, H, sub, _, _) in frames
+              for search in (_abi.RTMI_SEARCH_CONE_TREE, _abi.RTMI_SEARCH_LIST_SCAN)]
+    bufs = [f for f in frames for _ in range(2)]
+    torch.cuda.synchronize()
+    for p, (_, _, _, rgba, hit) in zip(params, bufs):  # first use of every kernel involved (code objects load lazily)
+        sc.render_device_noalloc(cam, p, rgba.data_ptr(), hit.data_ptr())
+    free0 = torch.cuda.mem_get_info()[0]
+    first = None
+    for i in range(120):
+        p, (_, _, _, rgba, hit) = params[i % 4], bufs[i % 4]
+        cnt = sc.render_device_noalloc(cam, p, rgba.data_ptr(), hit.data_ptr())
+        if i == 0:
+            first = (rgba.cpu().numpy().copy(), cnt["primary_hits"])
+        assert torch.cuda.mem_get_info()[0] == free0, f"free device memory changed at call {i}"
+    sc.render_device_noalloc(cam, params[0], bufs[0][3].data_ptr(), bufs[0][4].data_ptr())
+    assert (bufs[0][3].cpu().numpy() == first[0]).all() and first[1] > 0
+    sc.close()
+
+
+@pytest.mark.gpu
+def test_noalloc_calls_from_two_threads_take_turns(rt):
+    """Two scenes on one GPU share the device's static array; the library serialises their calls, so two threads
+    that call at the same time both get the frames a single thread gets."""
+    import threading
+    datas = [mixed_scene(rt.bounding_sphere), scenes.mesh_scene(3, "B", 3, bounding_sphere=rt.bounding_sphere)]
+    cam = scenes.make_camera(**CAM)
+    W, H, sub = FRAMES[0]
+    p = scenes.make_params(W, H, sub)
+    scs = [rt.Scene(d) for d in datas]
+    bufs = [torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda") for _ in datas]
+    torch.cuda.synchronize()
+    want = []
+    for sc, b in zip(scs, bufs):
+        sc.render_device_noalloc(cam, p, b.data_ptr())
+        want.append(b.cpu().numpy().copy())
+    bad = []
+
+    def work(k):
+        for _ in range(25):
+            b = bufs[k]
+            scs[k].render_device_noalloc(cam, p, b.data_ptr())
+            if not (b.cpu().numpy() == want[k]).all():
+                bad.append(k)
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not bad, f"frames of scene(s) {sorted(set(bad))} changed when two threads rendered at once"
+    for sc in scs:
+        sc.close()
 
 
 def test_noalloc_emulated_matches_oracle(oracle_mod, tmp_path):
