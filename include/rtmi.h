@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RTMI_ABI_VERSION 3
+#define RTMI_ABI_VERSION 4
 
 typedef enum {
   RTMI_OK = 0,
@@ -199,9 +199,16 @@ typedef struct {
   int64_t tri_tests_primary_kernel; /* pairs evaluated by the common-origin kernel       */
   double ms_primary_kernel; /* its accumulated launch time                               */
   double ms_shade;          /* device time of the shading launches                       */
-  int64_t primary_rays_traced; /* of samples: those whose ray was generated and tested with the reference's
-                                  arithmetic; the rest were cleared beforehand by a conservative test that shows
-                                  they can hit nothing (whole 8x8 blocks, then single samples)   */
+  int64_t primary_rays_traced; /* of samples: those whose ray was generated and went on to the sphere tests and the
+                                  triangle search; the rest were cleared beforehand by a conservative test that
+                                  shows they can hit nothing (whole 8x8 blocks, then single samples)   */
+  int64_t hits_decided_fp32;   /* frames of bounding-sphere-only scenes with RTMI_FLAG_NO_RAY_STATISTICS: (ray, triangle)
+                                  pairs accepted by conservative FP32 tests alone -- inside the triangle, its front and
+                                  the bounding sphere by margins that exceed the FP32 error; every other pair of
+                                  such a frame is counted in tri_exact_tests                          */
+  int64_t pixels_fixed_fp64;   /* the same frames: pixels whose bytes the FP32 lighting and its error bound could not
+                                  settle; every sample of such a pixel was shaded again with the reference's FP64
+                                  arithmetic                                                          */
 } rtmi_counters;
 
 typedef struct rtmi_scene rtmi_scene;

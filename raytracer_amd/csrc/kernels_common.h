@@ -71,7 +71,10 @@ struct FrameConst {
 
 // Work counters are striped over NSLOT slots (two 64-byte lines per slot) so that the
 // per-wave atomic adds of a launch do not serialise on one address; the host sums the slots.
-enum { C_REFL = 0, C_SHADOW, C_EXACT, C_HITS, C_TESTS_PRIMARY, C_TESTS_SECONDARY, C_SHADOW_ELIDED, C_NODE_TESTS, C_PRIMARY_TRACED, C_NCOUNTERS = 16 };
+enum { C_REFL = 0, C_SHADOW, C_EXACT, C_HITS, C_TESTS_PRIMARY, C_TESTS_SECONDARY, C_SHADOW_ELIDED, C_NODE_TESTS, C_PRIMARY_TRACED,
+       C_FIX_PIXELS,   // pixels whose bytes the FP32 lighting could not settle: evaluated again in FP64 (k_fix_pixels)
+       C_FP32_DECIDED, // single candidates accepted by the FP32 tests alone (inside the triangle and the bounding sphere by a margin)
+       C_NCOUNTERS = 16 };
 constexpr int NSLOT = 64;
 
 struct DevCounters {
@@ -87,6 +90,8 @@ struct DevCounters {
   // Two sets, used alternately by successive search launches of a frame: the last kernel of a
   // launch clears the set of the launch before it.
   int cand_n[2][NSLOT][16];
+  // pixels waiting for k_fix_pixels, in NSLOT lists (workgroup w of k_resolve_fast appends to list w & 63)
+  int fix_n[NSLOT][16];
 };
 
 struct SceneDev {

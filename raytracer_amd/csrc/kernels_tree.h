@@ -77,17 +77,116 @@ __device__ __forceinline__ void cand_flush(const SearchArgs* ap, const int2* sta
   for (int i = lane; i < fill; i += 64) cand[i] = stage[i];
 }
 
+// ---------------------------------------------------------------------------------------
+// the search without a ray-generation launch (see search_tree_body<R, true>)
+// ---------------------------------------------------------------------------------------
+constexpr int SURE_BIT = 1 << 30;  // in a candidate's list position: the FP32 edge test puts the ray inside the triangle by a margin
+
+// Per frame and top-level object (all of them bounding spheres here): Sphere.intersections (Renderables.swift:248-282)
+// with a = -d.cte and delta = a^2 - k answers "hit" for certain when a and delta exceed the FP32 evaluation error.
+struct SphereF {
+  float cx, cy, cz;  // camera - centre (the FP64 difference, rounded once)
+  float k;           // |camera - centre|^2 - radius^2 (FP64, rounded)
+  float ea;          // bound on |a - a*|: (dir_err + 8 * 2^-24) * |camera - centre|_1
+  float kabs;        // |k|
+  float pad0, pad1;
+};
+
+struct FastArgs {
+  const int2* blocks;   // the batch's 8x8 pixel blocks
+  int nsamples;         // blocks x 64 x samples per pixel
+  int obj;              // list index of the bounding sphere whose children this launch searches
+  int init_hit;         // this launch writes hit_id = -1 for every rendered sample of the batch (the first group's launch)
+  float dir_err;        // bound on |d - d*| for the FP32 directions of fast_dir (host: fast_dir_err)
+  int n_materials;
+  int* hit_id;
+  float4* rgbf;               // per sample: colour and its error bound (rtx32::Shade32)
+  const float4* pos_plane;    // per list position of the group: unit normal, c - n.camera (k_pack_tree)
+  const int2* pos_mt;         // per list position: the triangle's material index and its index in the scene's triangle array
+  int ns_uniform;             // the specular exponent if every material of the scene has the same one, else 0
+  const rtx32::LightF* lights;
+  const rtx32::MatF* mats;
+  const SphereF* spheres;
+  int* fix_list;              // pixels for k_fix_pixels: NSLOT lists of fix_cap / NSLOT entries
+  int fix_cap;
+  int force;                  // tests: bit 0 = no pair is accepted by the FP32 margins, bit 1 = every pixel goes to k_fix_pixels
+};
+
+// The FP32 direction of sub-sample (kx, ky) of pixel (x, y): pixelToWorldCoordinate (WorldCoordinateSequence.swift:62-66)
+// minus the camera, from the FP32 copies of the per-column and per-row tables, normalised with v_rsq_f32.  *f2_out gets
+// the squared length before normalisation, fx.. the unnormalised vector (the pre-test of the caller wants them).
+__device__ __forceinline__ void fast_dir(const FrameConst& fc, int x, int y, int kx, int ky, float* dx, float* dy, float* dz,
+                                         float* fx_out, float* fy_out, float* fz_out, float* dd_out) {
+  const float* uc = as_global(fc.utab_f) + (size_t)(x * fc.n1 + kx) * 3;
+  const float* vc = as_global(fc.vtab_f) + (size_t)(y * fc.n1 + ky) * 3;
+  const float fx = fc.base_f[0] + uc[0] - vc[0], fy = fc.base_f[1] + uc[1] - vc[1], fz = fc.base_f[2] + uc[2] - vc[2];
+  const float dd = fx * fx + fy * fy + fz * fz;
+  const float inv = rtx32::rsq(dd);
+  *dx = fx * inv; *dy = fy * inv; *dz = fz * inv;
+  *fx_out = fx; *fy_out = fy; *fz_out = fz; *dd_out = dd;
+}
+
+// Pixel and sub-sample of sample s of the batch (s = ((block * spp + k) << 6) + pixel of the 8x8 block).
+__device__ __forceinline__ void fast_sample_coords(const FrameConst& fc, const int2* __restrict__ blocks, int s, int* x, int* y,
+                                                   int* kx, int* ky) {
+  int b;
+  group_coords(fc, s >> 6, &b, kx, ky);
+  const int2 bc = blocks[b];
+  const int pix = s & (BLK_PIX - 1);
+  *x = bc.x * BLK + (pix & (BLK - 1));
+  *y = bc.y * BLK + (pix >> 3);
+}
+
+// The R rays of a lane in the search without a ray-generation launch.  A sample whose pixel is not rendered, whose
+// block k_block_cull cleared, or whose direction stays clear of the bounding sphere's cone (the pre-test that k_gen
+// applies in the other path, same operands) gets sid = -1 and a NaN direction.  Returns false if the wave has no ray.
+template <int R>
+__device__ __forceinline__ bool fast_prologue(const FrameConst& fc, const FastArgs& fa, DevCounters* cnt, int wave, int lane,
+                                              int (&sid)[R], float (&dx)[R], float (&dy)[R], float (&dz)[R]) {
+  const float qnan = __builtin_nanf("");
+  const float4 gf = fc.genf[fa.obj];
+  bool any = false;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int t = wave * R + r;  // wave-uniform: a group of 64 samples = the 64 pixels of one block at one sub-sample
+    sid[r] = -1;
+    dx[r] = dy[r] = dz[r] = qnan;
+    if ((t << 6) >= fa.nsamples) continue;
+    int b, kx, ky;
+    group_coords(fc, t, &b, &kx, &ky);
+    if (fc.block_live && fc.block_live[b] == 0) continue;  // wave-uniform
+    int x, y;
+    if (!pixel_coords(fc, fa.blocks, b, lane, &x, &y)) continue;
+    const int s = (t << 6) + lane;
+    if (fa.init_hit) fa.hit_id[s] = -1;
+    float ux, uy, uz, fx, fy, fz, dd;
+    fast_dir(fc, x, y, kx, ky, &ux, &uy, &uz, &fx, &fy, &fz, &dd);
+    const float qd = gf.x * fx + gf.y * fy + gf.z * fz;
+    const bool maybe = gf.w <= 0.0f || (qd > 0.0f && !(qd * qd < gf.w * dd));
+    if (maybe) {
+      sid[r] = s;
+      dx[r] = ux; dy[r] = uy; dz[r] = uz;
+      any = true;
+    }
+  }
+  return __any(any);
+}
+
 // Each wave walks the tree depth first for its R*64 rays.  The walk is wave-uniform: `lvl`, the
 // record index `ri` and `masks` (one byte of children still to visit per level) live in scalar
 // registers.  Record (l, r) holds the cones of nodes 8r..8r+7 of level l; the children of node
 // (l, j) are record (l-1, j); level-0 nodes are triangle slots, and a level-0 record is not
 // pushed but evaluated per lane: every (ray, slot) pair that passes becomes a candidate.
-template <int R>
-__global__ void __launch_bounds__(256, R <= 4 ? 7 : 6)
-k_search_tree(const SearchArgs* __restrict__ ap, const f2* __restrict__ rec, const float* __restrict__ edge_all,
-              const int* __restrict__ slot_pos, int parity) {
+// FAST (scenes whose top-level list holds nothing but bounding spheres without a material, pixels only): there is no
+// ray-generation launch before this one.  The wave's R*64 rays are the samples base .. base + R*64 - 1 of the batch; a
+// lane derives its rays' directions in FP32 from the per-column and per-row tables (fast_prologue), and the candidates
+// carry a mark when the ray lies inside the triangle by the same margin that the filter allows outside it.
+template <int R, bool FAST>
+__device__ __forceinline__ void search_tree_body(const SearchArgs* __restrict__ ap, const f2* __restrict__ rec,
+                                                 const float* __restrict__ edge_all, const int* __restrict__ slot_pos, int parity,
+                                                 const FrameConst* fcp, const FastArgs* fap) {
   __shared__ int2 stage_all[4][CAND_STAGE];
-  const int nq = *ap->nq_ptr;
+  const int nq = FAST ? fap->nsamples : *ap->nq_ptr;
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int base = wave * 64 * R;
@@ -96,7 +195,11 @@ k_search_tree(const SearchArgs* __restrict__ ap, const f2* __restrict__ rec, con
 
   int sid[R];
   float dx[R], dy[R], dz[R];
-  search_prologue<R>(ap, base, nq, lane, sid, dx, dy, dz);
+  if constexpr (FAST) {
+    if (!fast_prologue<R>(*fcp, *fap, ap->cnt, wave, lane, sid, dx, dy, dz)) return;  // wave-uniform: none of its samples can hit anything
+  } else {
+    search_prologue<R>(ap, base, nq, lane, sid, dx, dy, dz);
+  }
   {
     int* best_pos = ap->best_pos;  // this launch decides these rays: no hit so far
     const bool nearest = ap->nearest != 0;
@@ -176,7 +279,10 @@ k_search_tree(const SearchArgs* __restrict__ ap, const f2* __restrict__ rec, con
             __builtin_amdgcn_wave_barrier();
           }
           if (pass) {
-            stage[fill + __popcll(bm & ((1ull << lane) - 1ull))] = make_int2(sid[r], pos);
+            // FAST: e <= -1 puts the ray inside all three edge planes by the margin that covers the FP32 evaluation
+            int mark = 0;
+            if constexpr (FAST) mark = e <= -1.0f ? SURE_BIT : 0;
+            stage[fill + __popcll(bm & ((1ull << lane) - 1ull))] = make_int2(sid[r], pos | mark);
             pos1[r] = pos1[r] == -1 ? pos : -2;
           }
           fill += n;
@@ -235,6 +341,21 @@ k_search_tree(const SearchArgs* __restrict__ ap, const f2* __restrict__ rec, con
   DevCounters* cnt = ap->cnt;
   wave_count(cnt, C_TESTS_PRIMARY, lane == 0 ? 8ull * n_leaf_rec * (unsigned long long)active : 0ull);
   wave_count(cnt, C_NODE_TESTS, lane == 0 ? 8ull * n_node_rec * (unsigned long long)active : 0ull);
+  if constexpr (FAST) wave_count(cnt, C_PRIMARY_TRACED, lane == 0 ? (unsigned long long)active : 0ull);
+}
+
+template <int R>
+__global__ void __launch_bounds__(256, R <= 4 ? 7 : 6)
+k_search_tree(const SearchArgs* __restrict__ ap, const f2* __restrict__ rec, const float* __restrict__ edge_all,
+              const int* __restrict__ slot_pos, int parity) {
+  search_tree_body<R, false>(ap, rec, edge_all, slot_pos, parity, nullptr, nullptr);
+}
+
+template <int R>
+__global__ void __launch_bounds__(256, R <= 4 ? 7 : 6)
+k_search_tree_fast(const SearchArgs* __restrict__ ap, const f2* __restrict__ rec, const float* __restrict__ edge_all,
+                   const int* __restrict__ slot_pos, int parity, FrameConst fc, FastArgs fa) {
+  search_tree_body<R, true>(ap, rec, edge_all, slot_pos, parity, &fc, &fa);
 }
 
 // One lane per candidate: the reference's own arithmetic in FP64; a hit competes for the ray's

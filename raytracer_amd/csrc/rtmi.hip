@@ -37,6 +37,7 @@
 
 #include "../../include/rtmi.h"
 #include "rtmi_exact.h"
+#include "rtmi_shade32.h"
 
 using rtx::d3;
 using rtx::TriPlane;
@@ -90,6 +91,7 @@ static int32_t guarded(F&& body) {
 #include "kernels_scan.h"
 #include "kernels_tree.h"
 #include "kernels_shade.h"
+#include "kernels_fast.h"
 
 // ---------------------------------------------------------------------------------------
 // host side
@@ -124,6 +126,22 @@ struct WorkBufs {
   unsigned char* block_live = nullptr;  // per block of the list: can any of its samples hit anything (k_block_cull)
   size_t cap_blocks = 0;
   DevCounters* cnt = nullptr;  // work counters, queue and list fill levels
+};
+
+// Work buffers of the frames that run without a ray-generation launch (kernels_fast.h), grown on demand like the others.
+// Per sample of a batch 24 bytes (outcome, lowest list position, colour with its bound) plus the candidate lists.
+struct FastBufs {
+  size_t cap_samples = 0;
+  int* hit_id = nullptr;
+  int* best_pos = nullptr;
+  float4* rgbf = nullptr;
+  int2* cand = nullptr;
+  size_t cap_cand = 0;
+  int* fix_list = nullptr;   // pixels for k_fix_pixels
+  size_t cap_fix = 0;
+  unsigned char* consts = nullptr;  // per frame: LightF per light, MatF per material, SphereF per object
+  size_t cap_consts = 0;
+  std::vector<unsigned char> consts_uploaded;  // what `consts` holds (the async copy reads it after the call returns)
 };
 
 // ---------------------------------------------------------------------------------------
@@ -223,6 +241,9 @@ struct TriGroup {
   // which operands the device holds: 0 none, 1 cone tree, 2 list scan -- and for which camera position
   int packed_for = 0;
   double packed_cam[3] = {0, 0, 0};
+  double packed_err = 0.0;      // the direction error the tree's margins were widened by (k_pack_tree)
+  float4* d_pos_plane = nullptr;  // per list position: the triangle's plane for the FP32 lighting (k_pack_tree)
+  int2* d_pos_mt = nullptr;       // per list position: material index, triangle index
 };
 
 struct rtmi_scene {
@@ -255,6 +276,7 @@ struct rtmi_scene {
   // per-batch work buffers: the scene's own (grown on demand), or for the duration of one
   // rtmi_render_device_noalloc call slices of the library's static device array
   WorkBufs wb;
+  FastBufs fast;
   bool no_alloc = false;  // the frame being enqueued must fit the buffers as they are
   std::vector<SearchArgs> h_sargs;   // one argument block per triangle group
   SearchArgs* d_sargs = nullptr;
@@ -264,6 +286,7 @@ struct rtmi_scene {
   float4* d_genf = nullptr;                // k_gen pre-test operands, one per sphere-like object
   std::vector<float4> genf_uploaded;
   std::vector<rtmi_light> h_lights;
+  std::vector<rtmi_material> h_materials;
   std::vector<int2> h_blocks;          // host copy of the block list last uploaded
   std::array<int, 9> blocks_key{};     // frame geometry + tile selection it was built for
   bool blocks_valid = false;
@@ -352,6 +375,10 @@ static int32_t alloc_group(TriGroup& g, const std::vector<int>& idx, const rtmi_
   HIP_TRY(hipMalloc(&g.d_nodes, sizeof(NodeCone) * th.n_node_buf));
   HIP_TRY(hipMalloc(&g.d_ticket, sizeof(unsigned int)));
   HIP_TRY(hipMemset(g.d_ticket, 0, sizeof(unsigned int)));
+  HIP_TRY(hipMalloc(&g.d_pos_plane, sizeof(float4) * n1));
+  HIP_TRY(hipMemset(g.d_pos_plane, 0, sizeof(float4) * n1));
+  HIP_TRY(hipMalloc(&g.d_pos_mt, sizeof(int2) * n1));
+  HIP_TRY(hipMemset(g.d_pos_mt, 0, sizeof(int2) * n1));
   g.tree.slot_tri = g.d_slot_tri;
   g.tree.slot_pos = g.d_slot_pos;
   g.tree.rec = g.d_rec;
@@ -440,8 +467,10 @@ extern "C" void rtmi_scene_destroy(rtmi_scene* sc) {
     (void)hipFree(g.d_group); (void)hipFree(g.d_keep); (void)hipFree(g.d_block_counts);
     (void)hipFree(g.d_cone); (void)hipFree(g.d_edge); (void)hipFree(g.d_packed_tri); (void)hipFree(g.d_npacked);
     (void)hipFree(g.d_slot_tri); (void)hipFree(g.d_slot_pos); (void)hipFree(g.d_rec); (void)hipFree(g.d_tedge);
-    (void)hipFree(g.d_nodes); (void)hipFree(g.d_ticket);
+    (void)hipFree(g.d_nodes); (void)hipFree(g.d_ticket); (void)hipFree(g.d_pos_plane); (void)hipFree(g.d_pos_mt);
   }
+  (void)hipFree(sc->fast.hit_id); (void)hipFree(sc->fast.best_pos); (void)hipFree(sc->fast.rgbf); (void)hipFree(sc->fast.cand);
+  (void)hipFree(sc->fast.fix_list); (void)hipFree(sc->fast.consts);
   (void)hipFree(sc->d_objects); (void)hipFree(sc->d_lights); (void)hipFree(sc->d_materials);
   (void)hipFree(sc->d_tris); (void)hipFree(sc->d_planes); (void)hipFree(sc->d_tri_owner);
   (void)hipFree(sc->d_trec); (void)hipFree(sc->d_gst2);
@@ -532,6 +561,7 @@ static int32_t scene_create_impl(const rtmi_scene_desc* desc, int32_t device, rt
   }
   sc->objects.assign(desc->objects, desc->objects + desc->n_objects);
   sc->h_lights.assign(desc->lights, desc->lights + desc->n_lights);
+  sc->h_materials.assign(desc->materials, desc->materials + desc->n_materials);
   sc->n_lights = desc->n_lights;
   sc->n_materials = desc->n_materials;
   sc->n_tris = desc->n_triangles;
@@ -719,10 +749,11 @@ static int32_t ensure_buffers(rtmi_scene* sc, size_t samples, size_t blocks) {
 }
 
 // Per-frame cone tree of one group for the frame's camera position.
-static int32_t pack_group_tree(rtmi_scene* sc, TriGroup& g, d3 cam) {
+static int32_t pack_group_tree(rtmi_scene* sc, TriGroup& g, d3 cam, double dir_err) {
   if (g.n == 0) return RTMI_OK;  // the records were zeroed at creation: nothing passes
   int nblocks = (g.tree.n_slots + TREE_BLOCK - 1) / TREE_BLOCK;
-  hipLaunchKernelGGL(k_pack_tree, dim3(nblocks), dim3(TREE_BLOCK), 0, sc->stream, sc->d_tris, sc->d_planes, g.tree, cam);
+  hipLaunchKernelGGL(k_pack_tree, dim3(nblocks), dim3(TREE_BLOCK), 0, sc->stream, sc->d_tris, sc->d_planes, g.tree, cam, dir_err,
+                     g.d_pos_plane, g.d_pos_mt);
   HIP_TRY(hipGetLastError());
   return RTMI_OK;
 }
@@ -860,6 +891,90 @@ static size_t max_batch_samples() {
     return x > 0 ? std::min<size_t>((size_t)x, MAX_BATCH_SAMPLES) : MAX_BATCH_SAMPLES;
   }();
   return v;
+}
+
+// RTMI_FAST=0: frames that qualify for the path without a ray-generation launch take the general path (for comparison).
+static bool fast_enabled() {
+  static bool v = [] {
+    const char* e = getenv("RTMI_FAST");
+    return !(e && atoi(e) == 0);
+  }();
+  return v;
+}
+// RTMI_FAST_FORCE (tests): bit 0 = every (ray, triangle) pair of such a frame is decided in FP64, bit 1 = every pixel is
+// shaded again in FP64 -- the two fallbacks of the path, each made the rule.
+static int fast_force() {
+  static int v = [] {
+    const char* e = getenv("RTMI_FAST_FORCE");
+    return e ? atoi(e) & 3 : 0;
+  }();
+  return v;
+}
+constexpr int FAST_MAX_OBJECTS = 8;
+constexpr int FAST_MAX_MATERIALS = 4096;
+
+// Bound on |d - d*| for the FP32 sample directions of fast_dir, d* being the reference's FP64 unit direction
+// (normalize(pixelToWorldCoordinate(...) - camera), WorldCoordinateSequence.swift:62-66, RayTracingFunctions.swift:73).
+// fast_dir evaluates f = (base + uComponent) - vComponent with base = float(ul - camera) and the two components
+// rounded to float from the FP64 tables: per axis k the three roundings and two additions err by at most
+// 3 * 2^-24 * B_k, B_k = |base_k| + max|uComponent_k| + max|vComponent_k|; the reference's own FP64 roundings (it adds
+// ul first and subtracts the camera last) differ from the exact value by a few 2^-53 of |ul|_1 + |camera|_1 + B.  A vector
+// that is e away from f* normalises to a unit vector at most 2 e / |f*| away from d*, and |f*| is at least the distance
+// dmin from the camera to the focal plane; the FP32 normalisation itself (three products, two sums, v_rsq_f32 at 1 ulp,
+// three products) stays within 8 * 2^-24.  The result carries a factor 1.5 on top; tests/test_fast_path_math.py
+// compares it with observed errors.  Returns +inf when the frame has no usable bound.
+static double fast_dir_err(const FrameConst& fc, const rtmi_camera* cam) {
+  const double u32 = 5.9604644775390625e-08;
+  const double dlen = sqrt(cam->dir[0] * cam->dir[0] + cam->dir[1] * cam->dir[1] + cam->dir[2] * cam->dir[2]);
+  const double dmin = fabs(cam->focal_length) * dlen;
+  double b2 = 0.0, big = 0.0;
+  for (int k = 0; k < 3; ++k) {
+    const double bk = fabs(fc.ul[k] - fc.cam[k]) + fabs(fc.u[k]) * ((double)fc.W / fabs(fc.ppw_h)) + fabs(fc.v[k]) * ((double)fc.H / fabs(fc.ppw_v));
+    b2 += bk * bk;
+    big += fabs(fc.ul[k]) + fabs(fc.cam[k]) + bk;
+  }
+  const double ef = 3.0 * u32 * sqrt(b2) + 1.0e-15 * big;
+  const double err = 1.5 * (2.0 * ef / dmin + 8.0 * u32);
+  return std::isfinite(err) && dmin > 0 ? err : INFINITY;
+}
+
+static int32_t ensure_fast_buffers(rtmi_scene* sc, size_t samples, size_t pixels, size_t consts_bytes) {
+  FastBufs& f = sc->fast;
+  if (samples > f.cap_samples) {
+    (void)hipFree(f.hit_id); (void)hipFree(f.best_pos); (void)hipFree(f.rgbf); (void)hipFree(f.cand);
+    f.hit_id = f.best_pos = nullptr;
+    f.rgbf = nullptr;
+    f.cand = nullptr;
+    f.cap_samples = 0;
+    HIP_TRY(hipMalloc(&f.hit_id, sizeof(int) * samples));
+    HIP_TRY(hipMalloc(&f.best_pos, sizeof(int) * samples));
+    HIP_TRY(hipMalloc(&f.rgbf, sizeof(float4) * samples));
+    f.cap_cand = 2 * samples + (size_t)NSLOT * 16384;  // as ensure_buffers
+    if (const char* e = getenv("RTMI_CAND_CAPACITY")) {
+      const long long v = atoll(e);
+      if (v > 0) f.cap_cand = (size_t)std::max<long long>(v, NSLOT);
+    }
+    HIP_TRY(hipMalloc(&f.cand, sizeof(int2) * f.cap_cand));
+    f.cap_samples = samples;
+  }
+  // a list of k_resolve_fast holds every pixel of the workgroups that append to it
+  const size_t fix = ((pixels + 255) / 256 + NSLOT - 1) / NSLOT * 256 * NSLOT;
+  if (fix > f.cap_fix) {
+    (void)hipFree(f.fix_list);
+    f.fix_list = nullptr;
+    f.cap_fix = 0;
+    HIP_TRY(hipMalloc(&f.fix_list, sizeof(int) * fix));
+    f.cap_fix = fix;
+  }
+  if (consts_bytes > f.cap_consts) {
+    (void)hipFree(f.consts);
+    f.consts = nullptr;
+    f.cap_consts = 0;
+    f.consts_uploaded.clear();
+    HIP_TRY(hipMalloc(&f.consts, consts_bytes));
+    f.cap_consts = consts_bytes;
+  }
+  return RTMI_OK;
 }
 
 // Enqueue a whole frame on the scene's stream; nothing here waits for the device.  The caller
@@ -1035,9 +1150,7 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
   const size_t samples_per_block = (size_t)BLK_PIX * spp;
   const size_t blocks_per_batch = std::max<size_t>(1, max_batch_samples() / samples_per_block);
   const size_t max_batch_blocks = std::min(blocks_per_batch, std::max<size_t>(blocks.size(), 1));
-  int32_t rc = ensure_buffers(sc, max_batch_blocks * samples_per_block, std::max<size_t>(blocks.size(), 1));
-  if (rc) return rc;
-  sc->dev.n_samples = (int)std::min<size_t>(sc->wb.cap_samples, 0x7fffffff);
+  int32_t rc = RTMI_OK;
 
   hipStream_t st = sc->stream;
   HIP_TRY(hipEventRecord(sc->ev_a, st));
@@ -1082,6 +1195,82 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
       fc.n_genf = (int)gf.size();
     }
   }
+  // The frame without a ray-generation launch (kernels_fast.h): pixels only, every member of the list a bounding sphere
+  // without a material, whole-number specular exponents, the reference's hit policy, the cone tree.
+  bool fast = false;
+  double dir_err = 0.0;
+  if (fast_enabled() && use_tree && !nearest && !ext && !sc->no_alloc && sc->inert_secondary && !sc->lean_may_defer &&
+      (p->flags & RTMI_FLAG_NO_RAY_STATISTICS) != 0 && singles_enabled() && fc.n_genf > 0 && fc.n_genf == sc->dev.n_objects &&
+      sc->dev.n_objects <= FAST_MAX_OBJECTS && sc->n_materials <= FAST_MAX_MATERIALS && sc->n_lights <= FAST_LDS_LIGHTS) {
+    dir_err = fast_dir_err(fc, cam);
+    fast = dir_err < 1.0e-4;
+    for (const TriGroup& g : sc->groups) fast = fast && g.n < (1 << 30);
+  }
+  FastArgs fa{};
+  if (fast) {
+    const size_t consts_bytes = sizeof(rtx32::LightF) * std::max(1, sc->n_lights) + sizeof(rtx32::MatF) * std::max(1, sc->n_materials) +
+                                sizeof(SphereF) * sc->objects.size();
+    rc = ensure_fast_buffers(sc, max_batch_blocks * samples_per_block, max_batch_blocks * BLK_PIX, consts_bytes);
+    if (rc) return rc;
+    // the frame's constants for the FP32 lighting and the FP32 sphere test: FP64 differences and products, rounded once
+    std::vector<unsigned char> cb(consts_bytes, 0);
+    auto* lf = reinterpret_cast<rtx32::LightF*>(cb.data());
+    auto* mf = reinterpret_cast<rtx32::MatF*>(cb.data() + sizeof(rtx32::LightF) * std::max(1, sc->n_lights));
+    auto* sf = reinterpret_cast<SphereF*>(reinterpret_cast<unsigned char*>(mf) + sizeof(rtx32::MatF) * std::max(1, sc->n_materials));
+    auto up = [](double v) { return (float)(fabs(v) * 1.0000002); };  // a float that is not below |v|
+    for (int li = 0; li < sc->n_lights; ++li) {
+      const rtmi_light& L = sc->h_lights[(size_t)li];
+      const double lc[3] = {L.loc[0] - fc.cam[0], L.loc[1] - fc.cam[1], L.loc[2] - fc.cam[2]};
+      lf[li].lx = (float)lc[0]; lf[li].ly = (float)lc[1]; lf[li].lz = (float)lc[2];
+      lf[li].l1 = up(fabs(lc[0]) + fabs(lc[1]) + fabs(lc[2]));
+      lf[li].dr = (float)L.diffuse[0]; lf[li].dg = (float)L.diffuse[1]; lf[li].db = (float)L.diffuse[2];
+      lf[li].dmax = up(std::max(fabs(L.diffuse[0]), std::max(fabs(L.diffuse[1]), fabs(L.diffuse[2]))));
+      lf[li].sr = (float)L.specular[0]; lf[li].sg = (float)L.specular[1]; lf[li].sb = (float)L.specular[2];
+      lf[li].smax = up(std::max(fabs(L.specular[0]), std::max(fabs(L.specular[1]), fabs(L.specular[2]))));
+    }
+    for (int mi = 0; mi < sc->n_materials; ++mi) {
+      const rtmi_material& M = sc->h_materials[(size_t)mi];
+      const double ka[3] = {M.Ka[0] * fc.ambient[0], M.Ka[1] * fc.ambient[1], M.Ka[2] * fc.ambient[2]};  // RTF:193-196
+      mf[mi].ar = (float)ka[0]; mf[mi].ag = (float)ka[1]; mf[mi].ab = (float)ka[2];
+      mf[mi].amax = up(std::max(fabs(ka[0]), std::max(fabs(ka[1]), fabs(ka[2]))));
+      mf[mi].dr = (float)M.Kd[0]; mf[mi].dg = (float)M.Kd[1]; mf[mi].db = (float)M.Kd[2];
+      mf[mi].dmax = up(std::max(fabs(M.Kd[0]), std::max(fabs(M.Kd[1]), fabs(M.Kd[2]))));
+      mf[mi].sr = (float)M.Ks[0]; mf[mi].sg = (float)M.Ks[1]; mf[mi].sb = (float)M.Ks[2];
+      mf[mi].smax = up(std::max(fabs(M.Ks[0]), std::max(fabs(M.Ks[1]), fabs(M.Ks[2]))));
+      mf[mi].ns = (M.Ns >= 1.0 && M.Ns <= 64.0 && M.Ns == floor(M.Ns)) ? (int)M.Ns : 0;
+    }
+    for (size_t k = 0; k < sc->objects.size(); ++k) {
+      const rtmi_object& ob = sc->objects[k];
+      const double cte[3] = {fc.cam[0] - ob.center[0], fc.cam[1] - ob.center[1], fc.cam[2] - ob.center[2]};
+      const double kk = (cte[0] * cte[0] + cte[1] * cte[1] + cte[2] * cte[2]) - ob.radius * ob.radius;
+      sf[k].cx = (float)cte[0]; sf[k].cy = (float)cte[1]; sf[k].cz = (float)cte[2];
+      sf[k].k = (float)kk;
+      sf[k].ea = up((dir_err + 8.0 * 5.9604644775390625e-08) * (fabs(cte[0]) + fabs(cte[1]) + fabs(cte[2])));
+      sf[k].kabs = up(kk);
+      if (!std::isfinite(sf[k].k) || !std::isfinite(sf[k].ea)) sf[k].ea = INFINITY;  // never certain: the FP64 test decides
+    }
+    if (cb != sc->fast.consts_uploaded) {
+      sc->fast.consts_uploaded = cb;  // stays untouched until the next upload: the async copy reads it later
+      HIP_TRY(hipMemcpyAsync(sc->fast.consts, sc->fast.consts_uploaded.data(), consts_bytes, hipMemcpyHostToDevice, st));
+    }
+    fa.dir_err = (float)(dir_err * 1.0000002);
+    fa.n_materials = std::max(1, sc->n_materials);
+    fa.hit_id = sc->fast.hit_id;
+    fa.rgbf = sc->fast.rgbf;
+    fa.lights = reinterpret_cast<const rtx32::LightF*>(sc->fast.consts);
+    fa.mats = reinterpret_cast<const rtx32::MatF*>(sc->fast.consts + (reinterpret_cast<unsigned char*>(mf) - cb.data()));
+    fa.spheres = reinterpret_cast<const SphereF*>(sc->fast.consts + (reinterpret_cast<unsigned char*>(sf) - cb.data()));
+    fa.fix_list = sc->fast.fix_list;
+    fa.fix_cap = (int)std::min<size_t>(sc->fast.cap_fix, 0x7fffffff);
+    fa.force = fast_force();
+    fa.ns_uniform = sc->n_materials > 0 ? mf[0].ns : 0;
+    for (int mi = 1; mi < sc->n_materials; ++mi)
+      if (mf[mi].ns != mf[0].ns) fa.ns_uniform = 0;
+  }
+  // the general path's per-sample arrays are not needed by a frame of the other path; the block list is
+  rc = ensure_buffers(sc, fast ? 0 : max_batch_blocks * samples_per_block, std::max<size_t>(blocks.size(), 1));
+  if (rc) return rc;
+  sc->dev.n_samples = (int)std::min<size_t>(sc->wb.cap_samples, 0x7fffffff);
   if (!blocks_cached || !sc->blocks_valid) {
     if (!blocks.empty())
       HIP_TRY(hipMemcpyAsync(sc->wb.blocks, blocks.data(), sizeof(int2) * blocks.size(), hipMemcpyHostToDevice, st));
@@ -1115,8 +1304,10 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
   d3 camera = rtx::ld3(cam->pos);
   for (auto& g : sc->groups) {
     const int want = use_tree ? 1 : 2;
-    if (g.packed_for == want && memcmp(g.packed_cam, cam->pos, sizeof(g.packed_cam)) == 0) continue;
-    if ((rc = use_tree ? pack_group_tree(sc, g, camera) : pack_group(sc, g, camera))) return rc;
+    // (margins widened for a larger direction error than this frame's are still conservative)
+    if (g.packed_for == want && memcmp(g.packed_cam, cam->pos, sizeof(g.packed_cam)) == 0 && (!use_tree || g.packed_err >= dir_err)) continue;
+    if ((rc = use_tree ? pack_group_tree(sc, g, camera, dir_err) : pack_group(sc, g, camera))) return rc;
+    g.packed_err = dir_err;
     g.packed_for = want;
     memcpy(g.packed_cam, cam->pos, sizeof(g.packed_cam));
   }
@@ -1132,7 +1323,7 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
     a.packed_tri = g.d_packed_tri;
     a.dirs = sc->wb.dirs;
     a.tval = sc->wb.tval;
-    a.hit_id = sc->wb.hit_id;
+    a.hit_id = fast ? sc->fast.hit_id : sc->wb.hit_id;
     a.tri_hit = sc->wb.tri_hit;
     a.q_shade = sc->wb.q_shade;
     a.cnt = sc->wb.cnt;
@@ -1142,13 +1333,13 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
     a.mode = gi == 0 ? 1 : 0;
     a.obj_filter = g.object;
     a.group = g.d_group;
-    a.best_pos = sc->wb.best_pos;
-    a.cand = sc->wb.cand;
+    a.best_pos = fast ? sc->fast.best_pos : sc->wb.best_pos;
+    a.cand = fast ? sc->fast.cand : sc->wb.cand;
     a.n_group = g.n;
-    a.n_samples = (int)std::min<size_t>(sc->wb.cap_samples, 0x7fffffff);
+    a.n_samples = (int)std::min<size_t>(fast ? sc->fast.cap_samples : sc->wb.cap_samples, 0x7fffffff);
     a.n_tris = (int)sc->n_tris;
     a.n_records = (int)g.n_records;
-    a.cand_cap = (int)std::min<size_t>(sc->wb.cap_cand, 0x7fffffff);
+    a.cand_cap = (int)std::min<size_t>(fast ? sc->fast.cap_cand : sc->wb.cap_cand, 0x7fffffff);
     a.nearest = nearest ? 1 : 0;
     // bounded groups under the reference's hit policy, shaded by k_shade_candidates (which decides the single
     // candidates itself); ~position must stay apart from every position
@@ -1193,6 +1384,39 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
     if (fc.block_live) fcb.block_live = fc.block_live + b0;
     if (b0 > 0) HIP_TRY(hipMemsetAsync(&sc->wb.cnt->q_child, 0, sizeof(int) * 3, st));  // the first batch starts from the cleared counters
     int grid = (nsamples + 255) / 256;
+    if (fast) {
+      const int SRf = search_rays_per_lane(true, nsamples);
+      const int fgrid = (nsamples + 256 * SRf - 1) / (256 * SRf);
+      auto tree_fast = SRf == 8 ? k_search_tree_fast<8> : (SRf == 2 ? k_search_tree_fast<2> : k_search_tree_fast<4>);
+      fa.blocks = d_blk;
+      fa.nsamples = nsamples;
+      if (b0 > 0) HIP_TRY(hipMemsetAsync(&sc->wb.cnt->fix_n[0][0], 0, sizeof(sc->wb.cnt->fix_n), st));
+      for (size_t gi = 1; gi < sc->groups.size(); ++gi) {
+        TriGroup& g = sc->groups[gi];
+        hipEvent_t* ev;
+        if ((rc = next_events(&ev))) return rc;
+        HIP_TRY(hipEventRecord(ev[0], st));
+        const int par = launch_parity;
+        launch_parity ^= 1;
+        fa.obj = g.object;
+        fa.init_hit = gi == 1 ? 1 : 0;
+        fa.pos_plane = g.d_pos_plane;
+        fa.pos_mt = g.d_pos_mt;
+        hipLaunchKernelGGL(tree_fast, dim3(fgrid), dim3(256), 0, st, sc->d_sargs + gi, (const f2*)g.d_rec, (const float*)g.d_tedge,
+                           (const int*)g.d_slot_pos, par, fcb, fa);
+        hipLaunchKernelGGL(k_search_exact_multi_fast, dim3(sc->exact_grid), dim3(256), 0, st, sc->d_sargs + gi, par, fcb, fa);
+        HIP_TRY(hipEventRecord(ev[1], st));
+        hipLaunchKernelGGL(k_shade_candidates_fast, dim3(sc->exact_grid), dim3(256), 0, st, fcb, sc->dev, fa, sc->d_sargs + gi, par);
+        HIP_TRY(hipEventRecord(ev[2], st));
+        ++launches;
+      }
+      const int npix_f = (int)(nb * BLK_PIX);
+      hipLaunchKernelGGL(k_resolve_fast, dim3((npix_f + 255) / 256), dim3(256), 0, st, fcb, fa, npix_f, sc->wb.cnt, (unsigned char*)rgba_dev,
+                         (int*)hit_dev);
+      hipLaunchKernelGGL(k_fix_pixels, dim3(sc->exact_grid), dim3(256), 0, st, fcb, shc, sc->dev, fa, sc->wb.cnt, (unsigned char*)rgba_dev);
+      HIP_TRY(hipGetLastError());
+      continue;
+    }
     hipLaunchKernelGGL(k_gen, dim3((nsamples + 256 * GEN_ITERS - 1) / (256 * GEN_ITERS)), dim3(256), 0, st, fcb, sc->dev, d_blk, nsamples, sc->wb.hit_id, sc->wb.dirs, sc->wb.q_child,
                        sc->wb.q_shade, sc->wb.q_top, sc->wb.cnt, sc->wb.rgb);
     const int SR = search_rays_per_lane(use_tree, nsamples);
@@ -1430,6 +1654,8 @@ static int32_t render_finish(rtmi_scene* sc, rtmi_counters* counters) {
     counters->shadow_rays_elided = (int64_t)sum[C_SHADOW_ELIDED];
     counters->node_tests = (int64_t)sum[C_NODE_TESTS];
     counters->primary_rays_traced = (int64_t)sum[C_PRIMARY_TRACED];
+    counters->hits_decided_fp32 = (int64_t)sum[C_FP32_DECIDED];
+    counters->pixels_fixed_fp64 = (int64_t)sum[C_FIX_PIXELS];
     counters->tri_candidates = (int64_t)hc.cand_total;
     counters->ms_total = ms_total;
     counters->ms_tri_search = ms_search;

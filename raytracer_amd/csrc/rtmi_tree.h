@@ -335,10 +335,13 @@ __device__ inline float* rec_entry(float* rec, int rec_index, int j) {
 
 // Store the FP32 test vector of a node cone: w = axis / (cos - 2^-19), pass iff d.w >= 1 (the
 // margin covers the FP32 evaluation, see k_pack_write); NaN for a wide node, zero for an empty one.
-__device__ inline void store_cone(float* dst, NodeCone* nc) {
+// dir_err: how far the unit directions the search tests may be from the reference's (zero when they are the FP64
+// directions rounded to float; see fast_dir_err for the search that derives them in FP32): a direction d with
+// d*.axis >= cos still has d.axis >= cos - dir_err.
+__device__ inline void store_cone(float* dst, NodeCone* nc, double dir_err) {
   float wx = 0.f, wy = 0.f, wz = 0.f;
   if (nc->kind == 1) {
-    double den = nc->c - 1.9073486328125e-06;  // 2^-19
+    double den = nc->c - 1.9073486328125e-06 - dir_err;  // 2^-19
     wx = (float)(nc->ax / den); wy = (float)(nc->ay / den); wz = (float)(nc->az / den);
     if (!(den >= 0.0625) || !isfinite(wx) || !isfinite(wy) || !isfinite(wz)) nc->kind = 2;
   }
@@ -350,7 +353,8 @@ __device__ inline void store_cone(float* dst, NodeCone* nc) {
 // the workgroup that finishes last merges the remaining levels (a few thousand nodes at most
 // for a million triangles).
 __global__ void __launch_bounds__(TREE_BLOCK)
-k_pack_tree(const rtmi_triangle* __restrict__ tris, const TriPlane* __restrict__ planes, TreeDev T, d3 cam) {
+k_pack_tree(const rtmi_triangle* __restrict__ tris, const TriPlane* __restrict__ planes, TreeDev T, d3 cam, double dir_err,
+            float4* pos_plane, int2* pos_mt) {
   __shared__ NodeCone l0[TREE_BLOCK];
   __shared__ NodeCone l1[TREE_BLOCK / 8];
   __shared__ NodeCone l2[TREE_BLOCK / 64];
@@ -369,6 +373,11 @@ k_pack_tree(const rtmi_triangle* __restrict__ tris, const TriPlane* __restrict__
       const TriPlane pl = planes[ti];
       double num = pl.c - rtx::dp(rtx::mk(pl.nx, pl.ny, pl.nz), cam);
       keep = num < 0;  // false for NaN (degenerate triangle): never hit in the reference either
+      // the plane as the FP32 lighting reads it, filed under the triangle's list position (what a candidate carries)
+      if (pos_plane) {
+        pos_plane[T.slot_pos[p]] = make_float4((float)pl.nx, (float)pl.ny, (float)pl.nz, (float)num);
+        pos_mt[T.slot_pos[p]] = make_int2(tris[ti].material, ti);
+      }
     }
     if (keep) {
       const rtmi_triangle& t = tris[ti];
@@ -379,7 +388,7 @@ k_pack_tree(const rtmi_triangle* __restrict__ tris, const TriPlane* __restrict__
       double ls = sqrt(rtx::dp(sum, sum));
       d3 axis = rtx::divs(sum, ls);
       double cos_t = fmin(rtx::dp(axis, a), fmin(rtx::dp(axis, bb), rtx::dp(axis, c)));
-      if (cos_t - 1.9073486328125e-06 >= 0.0625) {  // false for NaN too
+      if (cos_t - 1.9073486328125e-06 - dir_err >= 0.0625) {  // false for NaN too
         nc.kind = 1;
         nc.ax = axis.x; nc.ay = axis.y; nc.az = axis.z;
         nc.c = cos_t;
@@ -396,13 +405,14 @@ k_pack_tree(const rtmi_triangle* __restrict__ tris, const TriPlane* __restrict__
       const double eps32 = 5.9604644775390625e-08;    // 2^-24
       const double abs_term = 9.094947017729282e-13;  // 2^-40
       for (int e = 0; e < 3; ++e) {
-        double E = 16.0 * eps32 * (fabs(M[e].x) + fabs(M[e].y) + fabs(M[e].z)) + abs_term * L * L;
+        // (a direction that is dir_err away from the reference's moves d.M by at most dir_err * |M|_2)
+        double E = (16.0 * eps32 + dir_err) * (fabs(M[e].x) + fabs(M[e].y) + fabs(M[e].z)) + abs_term * L * L;
         float mx = (float)(M[e].x / E), my = (float)(M[e].y / E), mz = (float)(M[e].z / E);
         if (!(E > 0) || !isfinite(mx) || !isfinite(my) || !isfinite(mz)) mx = my = mz = 0.0f;  // always nominate
         e9[e * 3 + 0] = mx; e9[e * 3 + 1] = my; e9[e * 3 + 2] = mz;
       }
     }
-    store_cone(rec_entry(T.rec, T.rec_off[0] + (p >> 3), p & 7), &nc);
+    store_cone(rec_entry(T.rec, T.rec_off[0] + (p >> 3), p & 7), &nc, dir_err);
     float* ed = T.edge + (size_t)p * EDGE_FLOATS;
     for (int q = 0; q < EDGE_FLOATS; ++q) ed[q] = e9[q];
   }
@@ -421,7 +431,7 @@ k_pack_tree(const rtmi_triangle* __restrict__ tris, const TriPlane* __restrict__
       if (1 <= T.ltop + 1 && g1 < T.n_nodes[1]) {
         unsigned always;
         m = merge_cones(&l0[tid * 8], 8, &always);
-        if (1 <= T.ltop) store_cone(rec_entry(T.rec, T.rec_off[1] + (g1 >> 3), g1 & 7), &m);
+        if (1 <= T.ltop) store_cone(rec_entry(T.rec, T.rec_off[1] + (g1 >> 3), g1 & 7), &m, dir_err);
         reinterpret_cast<unsigned*>(T.rec)[(size_t)(T.rec_off[0] + g1) * REC_DWORDS + REC_ALWAYS] = always;
       }
       l1[tid] = m;
@@ -435,7 +445,7 @@ k_pack_tree(const rtmi_triangle* __restrict__ tris, const TriPlane* __restrict__
       if (2 <= T.ltop + 1 && g2 < T.n_nodes[2]) {
         unsigned always;
         m = merge_cones(&l1[tid * 8], 8, &always);
-        if (2 <= T.ltop) store_cone(rec_entry(T.rec, T.rec_off[2] + (g2 >> 3), g2 & 7), &m);
+        if (2 <= T.ltop) store_cone(rec_entry(T.rec, T.rec_off[2] + (g2 >> 3), g2 & 7), &m, dir_err);
         reinterpret_cast<unsigned*>(T.rec)[(size_t)(T.rec_off[1] + g2) * REC_DWORDS + REC_ALWAYS] = always;
       }
       l2[tid] = m;
@@ -448,7 +458,7 @@ k_pack_tree(const rtmi_triangle* __restrict__ tris, const TriPlane* __restrict__
     if (g3 < T.n_nodes[3]) {
       unsigned always;
       NodeCone m = merge_cones(l2, 8, &always);
-      if (3 <= T.ltop) store_cone(rec_entry(T.rec, T.rec_off[3] + (g3 >> 3), g3 & 7), &m);
+      if (3 <= T.ltop) store_cone(rec_entry(T.rec, T.rec_off[3] + (g3 >> 3), g3 & 7), &m, dir_err);
       reinterpret_cast<unsigned*>(T.rec)[(size_t)(T.rec_off[2] + g3) * REC_DWORDS + REC_ALWAYS] = always;
       T.nodes[T.node_off[3] + g3] = m;
     }
@@ -469,7 +479,7 @@ k_pack_tree(const rtmi_triangle* __restrict__ tris, const TriPlane* __restrict__
         if (k < nv) ch[k] = T.nodes[T.node_off[L - 1] + j * 8 + k];
       unsigned always;
       NodeCone m = merge_cones(ch, nv, &always);
-      if (L <= T.ltop) store_cone(rec_entry(T.rec, T.rec_off[L] + (j >> 3), j & 7), &m);
+      if (L <= T.ltop) store_cone(rec_entry(T.rec, T.rec_off[L] + (j >> 3), j & 7), &m, dir_err);
       reinterpret_cast<unsigned*>(T.rec)[(size_t)(T.rec_off[L - 1] + j) * REC_DWORDS + REC_ALWAYS] = always;
       T.nodes[T.node_off[L] + j] = m;
     }

@@ -351,12 +351,15 @@ def test_emulated_pixels_only_flag_gives_the_same_frame(emu, oracle_mod, tmp_pat
     data = scenes.mesh_scene(1, "B", 3, bounding_sphere=oracle_mod.bounding_sphere)
     p = scenes.make_params(40, 32, 0.5, flags=_abi.RTMI_FLAG_NO_RAY_STATISTICS)
     o_rgba, o_hit, o_cnt = oracle_mod.render(data, cam, scenes.make_params(40, 32, 0.5), threads=4)
-    frames, stats, _ = emu.run_emulated(data, [cam, cam], p, tmp_path / "inert")
-    for rgba, hit, cnt in frames:
-        assert (hit[:31, :39] == o_hit[:31, :39]).all() and (rgba[:31, :39] == o_rgba[:31, :39]).all()
-        assert cnt.primary_hits == o_cnt["primary_hits"] > 0
-        assert cnt.rays_reflection == 0 and cnt.rays_shadow == 0 and cnt.shadow_rays_elided == 0
-    assert any("k_shade_candidates<false, true>" in k for k in stats)
+    for env, kernel in (({"RTMI_FAST": "0"}, "k_shade_candidates<false, true>"), (None, "k_shade_candidates_fast")):
+        # the general path's instantiation without secondary rays, then the path without a ray-generation launch
+        frames, stats, _ = emu.run_emulated(data, [cam, cam], p, tmp_path / ("inert" + kernel[-4:]), env=env)
+        for rgba, hit, cnt in frames:
+            assert (hit[:31, :39] == o_hit[:31, :39]).all() and (rgba[:31, :39] == o_rgba[:31, :39]).all()
+            assert cnt.primary_hits == o_cnt["primary_hits"] > 0
+            assert cnt.rays_reflection == 0 and cnt.rays_shadow == 0 and cnt.shadow_rays_elided == 0
+        assert any(kernel in k for k in stats), sorted(stats)
+        assert ("k_gen" in " ".join(stats)) == (env is not None)
     data.objects = np.concatenate([data.objects, scenes.sphere_object((1.9, 0.3, 0.4), 0.7, 0)])
     o_rgba, o_hit, o_cnt = oracle_mod.render(data, cam, scenes.make_params(40, 32, 0.5), threads=4)
     frames, stats, _ = emu.run_emulated(data, [cam], p, tmp_path / "not_inert")
@@ -389,3 +392,70 @@ def test_emulated_more_lights_than_the_trace_record_holds(emu, oracle_mod, tmp_p
         recorded = any("k_shade_replay<" in name for name in stats)
         assert recorded == (n == 16), sorted(stats)
         assert any("k_shade<true, " in name for name in stats) == (n == 17), sorted(stats)
+
+
+def bounded_spheres_scene(oracle_mod, n_groups=1, n_lights=3, extra_materials=False, level=2):
+    """Nothing but bounding spheres without a material in the list (what loadObjFile builds, one or several times):
+    the scenes of the path without a ray-generation launch.  With extra_materials the triangles use three materials
+    (exponents 8, 1 and 33) and every seventh triangle has none."""
+    parts, objs, first = [], [], 0
+    for g in range(n_groups):
+        v, f = scenes.displaced_icosphere(level if g == 0 else 1)
+        tr = scenes.triangles_from_vertices(v * (1.0 - 0.35 * g) + np.array([0.9 * g, -0.3 * g, 0.6 * g]), f, 0)
+        c, r = oracle_mod.bounding_sphere(tr)
+        objs.append(scenes.sphere_object(c, r, -1, bounding=True, first=first, count=len(tr)))
+        parts.append(tr)
+        first += len(tr)
+    tris = np.concatenate(parts)
+    mats = scenes.material(**scenes.VC_MATERIAL)
+    if extra_materials:
+        mats = np.concatenate([mats, scenes.material(1.0, 1.0, 2, (0.9, 0.2, 0.1), (0.3, 0.6, 0.1), (0.2, 0.2, 0.9)),
+                               scenes.material(33.0, 1.0, 2, (0.1, 0.4, 0.7), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0))])
+        tris["material"] = np.arange(len(tris)) % 3
+        tris["material"][::7] = -1
+    lights = np.concatenate([scenes.light(**L) for L in (scenes.L1, scenes.L2, scenes.L3)[:n_lights]])
+    return scenes.SceneData(lights=lights, materials=mats, objects=np.concatenate(objs), triangles=tris)
+
+
+FAST_CASES = [
+    # groups, materials, (W, H, sub), params extras, env
+    (1, False, (40, 32, 0.25), {}, None),
+    (1, True, (37, 29, 1.0), {}, None),
+    (1, True, (33, 27, 1.0 / 3.0), {}, None),                                 # 9 samples per pixel: groups of 64 samples straddle blocks
+    (1, False, (40, 32, 0.5), {"window": (5, 3, 31, 22)}, None),
+    (1, True, (48, 40, 0.5), {"tile_size": 8, "tile_rank": 1, "tile_world": 3}, None),
+    (1, False, (48, 40, 0.5), {"tile_size": 12, "tile_rank": 0, "tile_world": 2}, None),   # tiles that cut 8x8 blocks
+    (3, True, (44, 36, 0.5), {}, None),                                       # later groups are always decided in FP64
+    (2, False, (40, 32, 0.5), {}, {"RTMI_MAX_BATCH_SAMPLES": "2048"}),        # several batches
+    (1, True, (40, 32, 0.5), {}, {"RTMI_CAND_CAPACITY": "64"}),               # overflow: rendered again by the list scan
+    (1, True, (40, 32, 0.5), {}, {"RTMI_FAST_FORCE": "1"}),                   # every pair decided in FP64
+    (1, True, (40, 32, 0.5), {}, {"RTMI_FAST_FORCE": "2", "EMU_SEED": "3"}),  # every pixel shaded again in FP64
+    (2, True, (36, 30, 0.25), {}, {"RTMI_FAST_FORCE": "3", "RTMI_SEARCH_R": "4"}),
+]
+
+
+@pytest.mark.parametrize("case", range(len(FAST_CASES)))
+def test_emulated_frames_without_a_ray_generation_launch(emu, oracle_mod, tmp_path, case):
+    """Pixels only on scenes of bounding spheres: FP32 directions from the sample tables, candidates decided by FP32
+    margins or in FP64, FP32 lighting with an error bound, the pixels it cannot settle shaded again in FP64.  Hit ids and
+    bytes must be the oracle's, for three camera positions in a row on one scene object (one of them inside the mesh)."""
+    n_groups, mats, (W, H, sub), extra, env = FAST_CASES[case]
+    data = bounded_spheres_scene(oracle_mod, n_groups, extra_materials=mats)
+    cams = [scenes.make_camera(**scenes.MESH_CAMERA), scenes.make_camera((0.7, 0.4, 3.6), (-0.15, -0.1, -1.0), 7.0),
+            scenes.make_camera((0.05, 0.0, 0.3), (0.0, 0.2, -1.0), 3.0), scenes.make_camera(**scenes.MESH_CAMERA)]
+    p = scenes.make_params(W, H, sub, flags=_abi.RTMI_FLAG_NO_RAY_STATISTICS, **extra)
+    expected = [oracle_mod.render(data, c, p, threads=8)[:2] + (None,) for c in cams]
+    frames, stats, _ = emu.run_emulated(data, cams, p, tmp_path, env=env)
+    check_frames(frames, stats, expected, p)
+    names = " ".join(stats)
+    overflowed = bool(env and "RTMI_CAND_CAPACITY" in env)  # such a frame is rendered again by the general path's list scan
+    assert "k_shade_candidates_fast" in names and "k_resolve_fast" in names and ("k_gen" in names) == overflowed
+    hits = sum(int(o[2]["primary_hits"]) for o in [oracle_mod.render(data, c, p, threads=8) for c in cams[:1]])
+    assert frames[0][2].primary_hits == hits > 0
+    force = int((env or {}).get("RTMI_FAST_FORCE", "0"))
+    if force & 1:
+        assert all(f[2].hits_decided_fp32 == 0 for f in frames)
+    elif n_groups == 1 and not overflowed:
+        assert frames[0][2].hits_decided_fp32 > 0.9 * frames[0][2].primary_hits
+    if force & 2:
+        assert frames[0][2].pixels_fixed_fp64 >= (frames[0][1][..., 0] >= 0).sum()

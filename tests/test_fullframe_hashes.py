@@ -79,6 +79,64 @@ def test_whole_frame_equals_the_oracles(rt, name):
     sc.close()
 
 
+@pytest.mark.parametrize("name", [n for n in ("C2", "C3", "C4", "C5_step05", "C5_step16", "C5_step48") if n in GOLDEN])
+def test_whole_frame_pixels_only_equals_the_oracles(rt, name):
+    """The same frames asked for with RTMI_FLAG_NO_RAY_STATISTICS -- what bench.py times.  These scenes (one bounding
+    sphere without a material) then take the path without a ray-generation launch: FP32 directions, decisions by FP32
+    margins or in FP64, FP32 lighting with an error bound and an FP64 second pass for the pixels it cannot settle.  Same
+    bar: the oracle's digests of bitmap and hit ids.  Once more with each of the path's two fallbacks made the rule
+    (RTMI_FAST_FORCE is read when the library first renders, so those run in child processes)."""
+    rec = GOLDEN[name]
+    sc = rt.Scene(scene_for(rec, rt))
+    cam = camera_for(rec)
+    p = scenes.make_params(rec["width"], rec["height"], rec["subdivision"], flags=_abi.RTMI_FLAG_NO_RAY_STATISTICS)
+    for rep in range(2):  # the second frame reuses the camera's preparation
+        rgba, hit = buffers(rec, rt)
+        torch.cuda.synchronize()
+        cnt = sc.render_device(cam, p, rgba.data_ptr(), hit.data_ptr())
+        check_digest(f"{name} pixels only", dict(rec, counters={k: cnt[k] for k in COUNTERS}), rgba, hit, cnt)
+        assert cnt["primary_hits"] == rec["counters"]["primary_hits"] and cnt["samples"] == rec["counters"]["samples"]
+        assert cnt["rays_reflection"] == 0 and cnt["rays_shadow"] == 0
+        # the path is the one that ran: nearly every hit decided by the FP32 margins, a small share of the pixels shaded twice
+        assert cnt["hits_decided_fp32"] > 0.95 * cnt["primary_hits"], cnt
+        assert 0 < cnt["pixels_fixed_fp64"] < 0.2 * cnt["primary_hits"] / rt.samples_per_pixel(rec["subdivision"]), cnt
+        del rgba, hit
+    sc.close()
+
+
+@pytest.mark.parametrize("force", ["1", "2", "3"])
+def test_pixels_only_fallbacks_made_the_rule(force):
+    """C2 with every pair decided in FP64 (1), every pixel shaded again in FP64 (2), both (3): the same digests."""
+    import subprocess
+    import sys
+    code = (
+        "import json, hashlib, sys, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "import raytracer_amd as rt\n"
+        "from raytracer_amd import _abi, scenes\n"
+        "rec = json.load(open(%r))['C2']\n"
+        "data = scenes.mesh_scene(rec['mesh_level'], rec['form'], rec['lights'], bounding_sphere=rt.bounding_sphere)\n"
+        "sc = rt.Scene(data)\n"
+        "W, H = rec['width'], rec['height']\n"
+        "rgba = torch.zeros((H, W, 4), dtype=torch.uint8, device='cuda:0')\n"
+        "hit = torch.full((H, W, 4), -1, dtype=torch.int32, device='cuda:0')\n"
+        "torch.cuda.synchronize()\n"
+        "p = scenes.make_params(W, H, rec['subdivision'], flags=_abi.RTMI_FLAG_NO_RAY_STATISTICS)\n"
+        "cnt = sc.render_device(scenes.make_camera(**scenes.MESH_CAMERA), p, rgba.data_ptr(), hit.data_ptr())\n"
+        "print(json.dumps({'rgba': hashlib.sha256(rgba.cpu().numpy().tobytes()).hexdigest(), 'hit': hashlib.sha256(hit.cpu().numpy().tobytes()).hexdigest(), 'cnt': cnt}))\n"
+    ) % (os.path.dirname(HERE), os.path.join(HERE, "golden", "fullframe_hashes.json"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RTMI_FAST_FORCE=force), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    rec = GOLDEN["C2"]
+    assert out["rgba"] == rec["rgba_sha256"] and out["hit"] == rec["hit_sha256"]
+    cnt = out["cnt"]
+    if int(force) & 1:
+        assert cnt["hits_decided_fp32"] == 0 and cnt["tri_exact_tests"] >= cnt["primary_hits"]
+    if int(force) & 2:
+        assert cnt["pixels_fixed_fp64"] >= cnt["primary_hits"] / 4
+
+
 def test_orbit_frames_through_begin_end_with_two_scene_objects(rt):
     """Config 5 the way bench.py drives it: consecutive camera positions, frames alternating between two scene
     objects (each with its own stream and work buffers), frame i enqueued before frame i-1 is waited for."""
