@@ -92,6 +92,11 @@ struct DevCounters {
   int cand_n[2][NSLOT][16];
   // pixels waiting for k_fix_pixels, in NSLOT lists (workgroup w of k_resolve_fast appends to list w & 63)
   int fix_n[NSLOT][16];
+  // the candidates of the rays that have several (SearchArgs::singles), in NSLOT lists like the candidates themselves
+  // and with two sets of fill levels like theirs; multi_overflow: a list did not fit (the decisions then scan every candidate)
+  int multi_n[2][NSLOT][16];
+  int multi_overflow;
+  int pad2[15];
 };
 
 struct SceneDev {

@@ -41,9 +41,10 @@ k_search_exact_multi_fast(const SearchArgs* __restrict__ ap, int parity, FrameCo
   unsigned int n_exact = 0;
   if (!cnt->overflow) {
     const int list = blockIdx.x & (NSLOT - 1), part = blockIdx.x / NSLOT, parts = gridDim.x / NSLOT;
-    const int list_cap = ap->cand_cap / NSLOT;
-    const int n = min(cnt->cand_n[parity][list][0], list_cap);
-    const auto* cand = as_global(ap->cand) + (size_t)list * list_cap;
+    const bool listed = !cnt->multi_overflow;  // as in k_search_exact_multi
+    const int list_cap = (listed ? ap->multi_cap : ap->cand_cap) / NSLOT;
+    const int n = min(listed ? cnt->multi_n[parity][list][0] : cnt->cand_n[parity][list][0], list_cap);
+    const auto* cand = as_global(listed ? ap->multi : ap->cand) + (size_t)list * list_cap;
     auto* best_pos = as_global(ap->best_pos);
     const d3 o = rtx::ld3(ap->cam);
     for (int i = part * blockDim.x + threadIdx.x; i < n; i += parts * blockDim.x) {

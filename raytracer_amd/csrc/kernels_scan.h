@@ -57,6 +57,8 @@ struct SearchArgs {
   int singles;       // tree search: a ray with exactly ONE candidate gets best_pos = ~position from k_search_tree; that
                      // pair is then decided in FP64 where the ray is shaded (k_shade_candidates), not by
                      // k_search_exact, which only serves the rays with several candidates
+  int2* multi;       // singles: the candidates of the rays that have several, NSLOT lists of multi_cap / NSLOT (may be null)
+  int multi_cap;
   TreeDev tree;
 };
 

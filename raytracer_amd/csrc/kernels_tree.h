@@ -13,6 +13,7 @@
 // waves per SIMD (the walk is a chain of dependent scalar loads; occupancy hides their latency)
 // and runs the FP64 tests with all 64 lanes busy.
 constexpr int CAND_STAGE = 512;  // candidates a wave collects in LDS before it reserves global space
+constexpr int MULTI_STAGE = 128; // the same for the candidates of rays with several (one step adds at most 2 x 64)
 // Nearest-hit policy: k_search_exact marks the candidates that are hits with this bit of their list position
 // (list positions stay below it: the host refuses larger groups) and lowers the ray's smallest parameter;
 // k_search_nearest then lets the marked candidates whose parameter IS that smallest one compete by position.
@@ -58,6 +59,7 @@ __device__ inline void search_lists_retire(DevCounters* cnt, int parity) {
   if (blockIdx.x == 0 && threadIdx.x < NSLOT) {
     atomicAdd(&cnt->cand_total, (unsigned long long)(unsigned int)cnt->cand_n[parity][threadIdx.x][0]);
     cnt->cand_n[parity ^ 1][threadIdx.x][0] = 0;
+    cnt->multi_n[parity ^ 1][threadIdx.x][0] = 0;
   }
 }
 
@@ -172,6 +174,23 @@ __device__ __forceinline__ bool fast_prologue(const FrameConst& fc, const FastAr
   return __any(any);
 }
 
+// The same for the wave's staged candidates of rays that have several.  A list that does not fit only costs time: the
+// decisions then scan every candidate (k_search_exact_multi).
+__device__ __forceinline__ void multi_flush(const SearchArgs* ap, const int2* mstage, int fill, int lane, int list, int parity) {
+  if (fill == 0) return;
+  DevCounters* cnt = ap->cnt;
+  const int list_cap = ap->multi_cap / NSLOT;
+  int base = 0;
+  if (lane == 0) base = atomicAdd(&cnt->multi_n[parity][list][0], fill);
+  base = __builtin_amdgcn_readfirstlane(base);
+  if (base + fill > list_cap || base < 0) {
+    if (lane == 0) cnt->multi_overflow = 1;
+    return;
+  }
+  int2* dst = ap->multi + (size_t)list * list_cap + base;
+  for (int i = lane; i < fill; i += 64) dst[i] = mstage[i];
+}
+
 // Each wave walks the tree depth first for its R*64 rays.  The walk is wave-uniform: `lvl`, the
 // record index `ri` and `masks` (one byte of children still to visit per level) live in scalar
 // registers.  Record (l, r) holds the cones of nodes 8r..8r+7 of level l; the children of node
@@ -186,12 +205,16 @@ __device__ __forceinline__ void search_tree_body(const SearchArgs* __restrict__ 
                                                  const float* __restrict__ edge_all, const int* __restrict__ slot_pos, int parity,
                                                  const FrameConst* fcp, const FastArgs* fap) {
   __shared__ int2 stage_all[4][CAND_STAGE];
+  __shared__ int2 mstage_all[4][MULTI_STAGE];
   const int nq = FAST ? fap->nsamples : *ap->nq_ptr;
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int base = wave * 64 * R;
   if (base >= nq) return;  // no workgroup-wide synchronisation below: waves leave on their own
   int2* stage = stage_all[threadIdx.x >> 6];
+  int2* mstage = mstage_all[threadIdx.x >> 6];
+  const bool singles = ap->singles != 0;
+  int mfill = 0;
 
   int sid[R];
   float dx[R], dy[R], dz[R];
@@ -283,9 +306,28 @@ __device__ __forceinline__ void search_tree_body(const SearchArgs* __restrict__ 
             int mark = 0;
             if constexpr (FAST) mark = e <= -1.0f ? SURE_BIT : 0;
             stage[fill + __popcll(bm & ((1ull << lane) - 1ull))] = make_int2(sid[r], pos | mark);
-            pos1[r] = pos1[r] == -1 ? pos : -2;
           }
           fill += n;
+          // a ray's second candidate takes its first one along to the list of candidates that need a decision among
+          // themselves; later ones join it
+          const int prev = pos1[r];
+          const bool again = pass && prev != -1;
+          if (pass) pos1[r] = prev == -1 ? pos : -2;
+          const unsigned long long m2 = singles ? __ballot(again) : 0ull;
+          if (m2) {
+            const bool first_too = again && prev >= 0;
+            const unsigned long long m1 = __ballot(first_too);
+            const int n2 = __popcll(m2), add = n2 + __popcll(m1);
+            if (mfill + add > MULTI_STAGE) {
+              multi_flush(ap, mstage, mfill, lane, wave & (NSLOT - 1), parity);
+              mfill = 0;
+              __builtin_amdgcn_wave_barrier();
+            }
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (again) mstage[mfill + __popcll(m2 & below)] = make_int2(sid[r], pos);
+            if (first_too) mstage[mfill + n2 + __popcll(m1 & below)] = make_int2(sid[r], prev);
+            mfill += add;
+          }
         }
       }
     }
@@ -327,7 +369,8 @@ __device__ __forceinline__ void search_tree_body(const SearchArgs* __restrict__ 
   }
   __builtin_amdgcn_wave_barrier();
   cand_flush(ap, stage, fill, lane, wave & (NSLOT - 1), parity);
-  if (ap->singles) {
+  multi_flush(ap, mstage, mfill, lane, wave & (NSLOT - 1), parity);
+  if (singles) {
     int* best_pos = ap->best_pos;
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -442,9 +485,11 @@ k_search_exact_multi(const SearchArgs* __restrict__ ap, int parity) {
   unsigned int n_exact = 0;
   if (!cnt->overflow) {
     const int list = blockIdx.x & (NSLOT - 1), part = blockIdx.x / NSLOT, parts = gridDim.x / NSLOT;
-    const int list_cap = ap->cand_cap / NSLOT;
-    const int n = min(cnt->cand_n[parity][list][0], list_cap);
-    const auto* cand = as_global(ap->cand) + (size_t)list * list_cap;
+    // the search listed these candidates apart (multi_flush); if that list did not fit, every candidate is looked at
+    const bool listed = !cnt->multi_overflow;
+    const int list_cap = (listed ? ap->multi_cap : ap->cand_cap) / NSLOT;
+    const int n = min(listed ? cnt->multi_n[parity][list][0] : cnt->cand_n[parity][list][0], list_cap);
+    const auto* cand = as_global(listed ? ap->multi : ap->cand) + (size_t)list * list_cap;
     auto* best_pos = as_global(ap->best_pos);
     const d3 o = rtx::ld3(ap->cam);
     for (int i = part * blockDim.x + threadIdx.x; i < n; i += parts * blockDim.x) {

@@ -120,6 +120,8 @@ struct WorkBufs {
   int* best_pos = nullptr;   // tree search: per sample, lowest list position hit
   int2* cand = nullptr;      // tree search: candidate pairs, cap_cand entries in NSLOT lists
   size_t cap_cand = 0;
+  int2* multi = nullptr;     // tree search: the candidates of rays that have several, cap_multi entries in NSLOT lists
+  size_t cap_multi = 0;
   double* tabs = nullptr;    // utab then vtab (FP64), then their FP32 copies
   size_t cap_tabs = 0;
   int2* blocks = nullptr;
@@ -137,6 +139,8 @@ struct FastBufs {
   float4* rgbf = nullptr;
   int2* cand = nullptr;
   size_t cap_cand = 0;
+  int2* multi = nullptr;
+  size_t cap_multi = 0;
   int* fix_list = nullptr;   // pixels for k_fix_pixels
   size_t cap_fix = 0;
   unsigned char* consts = nullptr;  // per frame: LightF per light, MatF per material, SphereF per object
@@ -299,6 +303,7 @@ struct rtmi_scene {
   // no reflection or shadow ray can change a pixel
   bool inert_secondary = false;
   int exact_grid = 2048;  // workgroups of the grid-stride k_search_exact: eight per compute unit
+  int fast_shade_grid = 1280;  // of k_shade_candidates_fast: as many as are resident at once (RTMI_SHADE_FAST_WAVES per SIMD)
   // one frame may be in flight between rtmi_render_begin and rtmi_render_end
   bool pending = false;
   DevCounters* h_cnt = nullptr;  // pinned host copy of the device counters
@@ -470,6 +475,7 @@ extern "C" void rtmi_scene_destroy(rtmi_scene* sc) {
     (void)hipFree(g.d_nodes); (void)hipFree(g.d_ticket); (void)hipFree(g.d_pos_plane); (void)hipFree(g.d_pos_mt);
   }
   (void)hipFree(sc->fast.hit_id); (void)hipFree(sc->fast.best_pos); (void)hipFree(sc->fast.rgbf); (void)hipFree(sc->fast.cand);
+  (void)hipFree(sc->fast.multi); (void)hipFree(sc->wb.multi);
   (void)hipFree(sc->fast.fix_list); (void)hipFree(sc->fast.consts);
   (void)hipFree(sc->d_objects); (void)hipFree(sc->d_lights); (void)hipFree(sc->d_materials);
   (void)hipFree(sc->d_tris); (void)hipFree(sc->d_planes); (void)hipFree(sc->d_tri_owner);
@@ -543,6 +549,10 @@ static int32_t scene_create_impl(const rtmi_scene_desc* desc, int32_t device, rt
     int per_cu = e ? atoi(e) : 8;
     if (per_cu < 1 || per_cu > 64) per_cu = 8;
     sc->exact_grid = ((std::max(1, prop.multiProcessorCount) * per_cu + NSLOT - 1) / NSLOT) * NSLOT;
+    const char* e2 = getenv("RTMI_FAST_SHADE_GRID_PER_CU");
+    int per_cu2 = e2 ? atoi(e2) : RTMI_SHADE_FAST_WAVES;
+    if (per_cu2 < 1 || per_cu2 > 64) per_cu2 = RTMI_SHADE_FAST_WAVES;
+    sc->fast_shade_grid = ((std::max(1, prop.multiProcessorCount) * per_cu2 + NSLOT - 1) / NSLOT) * NSLOT;
   }
   HIP_TRY(hipSetDevice(device));
   {
@@ -709,6 +719,9 @@ static int32_t ensure_buffers(rtmi_scene* sc, size_t samples, size_t blocks) {
     (void)hipFree(sc->wb.hit_id); (void)hipFree(sc->wb.tri_hit); (void)hipFree(sc->wb.q_child);
     (void)hipFree(sc->wb.q_shade); (void)hipFree(sc->wb.q_top); (void)hipFree(sc->wb.rgb);
     (void)hipFree(sc->wb.dirs); (void)hipFree(sc->wb.tval); (void)hipFree(sc->wb.best_pos); (void)hipFree(sc->wb.cand);
+    (void)hipFree(sc->wb.multi);
+    sc->wb.multi = nullptr;
+    sc->wb.cap_multi = 0;
     sc->wb.hit_id = sc->wb.tri_hit = sc->wb.q_child = sc->wb.q_shade = sc->wb.q_top = sc->wb.best_pos = nullptr;
     sc->wb.rgb = sc->wb.dirs = sc->wb.tval = nullptr;
     sc->wb.cand = nullptr;
@@ -732,6 +745,14 @@ static int32_t ensure_buffers(rtmi_scene* sc, size_t samples, size_t blocks) {
       if (v > 0) sc->wb.cap_cand = (size_t)std::max<long long>(v, NSLOT);
     }
     HIP_TRY(hipMalloc(&sc->wb.cand, sizeof(int2) * sc->wb.cap_cand));
+    // a closed mesh seen from outside gives a few rays in a hundred a second candidate; if this list does not fit,
+    // the decisions scan the candidate lists instead
+    sc->wb.cap_multi = std::min(sc->wb.cap_cand, samples / 2 + (size_t)NSLOT * 4096);
+    if (const char* e = getenv("RTMI_MULTI_CAPACITY")) {  // tests: a small value makes this list overflow
+      const long long v = atoll(e);
+      if (v > 0) sc->wb.cap_multi = (size_t)std::max<long long>(v, NSLOT);
+    }
+    HIP_TRY(hipMalloc(&sc->wb.multi, sizeof(int2) * sc->wb.cap_multi));
     sc->wb.cap_samples = samples;
   }
   if (blocks > sc->wb.cap_blocks) {
@@ -941,7 +962,9 @@ static double fast_dir_err(const FrameConst& fc, const rtmi_camera* cam) {
 static int32_t ensure_fast_buffers(rtmi_scene* sc, size_t samples, size_t pixels, size_t consts_bytes) {
   FastBufs& f = sc->fast;
   if (samples > f.cap_samples) {
-    (void)hipFree(f.hit_id); (void)hipFree(f.best_pos); (void)hipFree(f.rgbf); (void)hipFree(f.cand);
+    (void)hipFree(f.hit_id); (void)hipFree(f.best_pos); (void)hipFree(f.rgbf); (void)hipFree(f.cand); (void)hipFree(f.multi);
+    f.multi = nullptr;
+    f.cap_multi = 0;
     f.hit_id = f.best_pos = nullptr;
     f.rgbf = nullptr;
     f.cand = nullptr;
@@ -955,6 +978,12 @@ static int32_t ensure_fast_buffers(rtmi_scene* sc, size_t samples, size_t pixels
       if (v > 0) f.cap_cand = (size_t)std::max<long long>(v, NSLOT);
     }
     HIP_TRY(hipMalloc(&f.cand, sizeof(int2) * f.cap_cand));
+    f.cap_multi = std::min(f.cap_cand, samples / 2 + (size_t)NSLOT * 4096);
+    if (const char* e = getenv("RTMI_MULTI_CAPACITY")) {  // tests: a small value makes this list overflow
+      const long long v = atoll(e);
+      if (v > 0) f.cap_multi = (size_t)std::max<long long>(v, NSLOT);
+    }
+    HIP_TRY(hipMalloc(&f.multi, sizeof(int2) * f.cap_multi));
     f.cap_samples = samples;
   }
   // a list of k_resolve_fast holds every pixel of the workgroups that append to it
@@ -1340,6 +1369,8 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
     a.n_tris = (int)sc->n_tris;
     a.n_records = (int)g.n_records;
     a.cand_cap = (int)std::min<size_t>(fast ? sc->fast.cap_cand : sc->wb.cap_cand, 0x7fffffff);
+    a.multi = fast ? sc->fast.multi : sc->wb.multi;
+    a.multi_cap = (int)std::min<size_t>(fast ? sc->fast.cap_multi : sc->wb.cap_multi, 0x7fffffff);
     a.nearest = nearest ? 1 : 0;
     // bounded groups under the reference's hit policy, shaded by k_shade_candidates (which decides the single
     // candidates itself); ~position must stay apart from every position
@@ -1406,7 +1437,7 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
                            (const int*)g.d_slot_pos, par, fcb, fa);
         hipLaunchKernelGGL(k_search_exact_multi_fast, dim3(sc->exact_grid), dim3(256), 0, st, sc->d_sargs + gi, par, fcb, fa);
         HIP_TRY(hipEventRecord(ev[1], st));
-        hipLaunchKernelGGL(k_shade_candidates_fast, dim3(sc->exact_grid), dim3(256), 0, st, fcb, sc->dev, fa, sc->d_sargs + gi, par);
+        hipLaunchKernelGGL(k_shade_candidates_fast, dim3(sc->fast_shade_grid), dim3(256), 0, st, fcb, sc->dev, fa, sc->d_sargs + gi, par);
         HIP_TRY(hipEventRecord(ev[2], st));
         ++launches;
       }

@@ -100,63 +100,62 @@ RT_HD float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 #define RT_HD_FLAT inline __attribute__((always_inline))
 #endif
 RT_HD_FLAT Shade32 shade_hit(float dx, float dy, float dz, float dir_err, float nx, float ny, float nz, float num, const MatF& m,
-                        const LightF* lights, int n_lights, int ns_loop = 0) {
+                             const LightF* lights, int n_lights, int ns_loop = 0) {
+  // (fused multiply-adds are written out: the translation unit is built without contraction, and a fused operation
+  // only ever has less rounding error than the two the model above charges)
   const float inf = __builtin_inff();
   Shade32 out;
-  float er = 0.0f;
   bool flag = m.ns < 1;
-  const float nd = -(nx * dx + ny * dy + nz * dz);
+  const float nd = -__builtin_fmaf(nz, dz, __builtin_fmaf(ny, dy, nx * dx));
   const float dn = dir_err + 6.0f * U;
   if (!(nd > 8.0f * dn)) flag = true;
   const float rnd = rcp(nd);
   const float t = -num * rnd;
-  const float rho_t = dn * rnd + 6.0f * U;
+  const float rho_t = __builtin_fmaf(dn, rnd, 6.0f * U);
   const float px = t * dx, py = t * dy, pz = t * dz;
-  const float eP = fabsf(t) * (rho_t + dir_err + 2.0f * U);
+  const float eP = fabsf(t) * (rho_t + (dir_err + 2.0f * U));
   float r = m.ar, g = m.ag, b = m.ab;  // RTF:193-196
   float mag = m.amax;                  // sum of the magnitudes of the terms added so far (largest channel)
-  er += U * m.amax;
+  float er = U * m.amax;
 #pragma nounroll
   for (int li = 0; li < n_lights; ++li) {
     const LightF L = lights[li];
     const float vx = L.lx - px, vy = L.ly - py, vz = L.lz - pz;
-    const float ll = vx * vx + vy * vy + vz * vz;
+    const float ll = __builtin_fmaf(vz, vz, __builtin_fmaf(vy, vy, vx * vx));
     const float inv = rsq(ll);
     const float len = ll * inv;
-    const float eL = U * (L.l1 + 2.0f * len) + eP;
-    const float dndl = 2.0f * eL * inv + 14.0f * U;
+    const float eL = __builtin_fmaf(U, __builtin_fmaf(2.0f, len, L.l1), eP);
+    const float dndl = __builtin_fmaf(2.0f * eL, inv, 14.0f * U);
     const float hx = vx * inv, hy = vy * inv, hz = vz * inv;
-    const float ndl = hx * nx + hy * ny + hz * nz;
+    const float ndl = __builtin_fmaf(hz, nz, __builtin_fmaf(hy, ny, hx * nx));
     if (!(fabsf(ndl) > dndl)) flag = true;  // RTF:229-232 could go either way (also: NaN, a light at the hit point)
     if (!(ndl > 0.0f)) continue;
     // diffuse, RTF:246-249
-    const float kd_r = m.dr * L.dr, kd_g = m.dg * L.dg, kd_b = m.db * L.db;
-    r += kd_r * ndl; g += kd_g * ndl; b += kd_b * ndl;
+    r = __builtin_fmaf(m.dr * L.dr, ndl, r); g = __builtin_fmaf(m.dg * L.dg, ndl, g); b = __builtin_fmaf(m.db * L.db, ndl, b);
     const float kdmax = m.dmax * L.dmax;
-    mag += kdmax * ndl;
-    er += kdmax * (dndl + 6.0f * U * ndl);
+    mag = __builtin_fmaf(kdmax, ndl, mag);
+    er = __builtin_fmaf(kdmax, __builtin_fmaf(6.0f * U, ndl, dndl), er);
     // specular, RTF:251-266
     const float two = 2.0f * ndl;
-    const float rx = two * nx - hx, ry = two * ny - hy, rz = two * nz - hz;
-    const float rv = -(rx * dx + ry * dy + rz * dz);
-    const float drv = 3.0f * dndl + dir_err + 24.0f * U;
+    const float rx = __builtin_fmaf(two, nx, -hx), ry = __builtin_fmaf(two, ny, -hy), rz = __builtin_fmaf(two, nz, -hz);
+    const float rv = -__builtin_fmaf(rz, dz, __builtin_fmaf(ry, dy, rx * dx));
+    const float drv = __builtin_fmaf(3.0f, dndl, dir_err + 24.0f * U);
     if (rv + drv > 0.0f) {
       // rv* lies in [rv - drv, rv + drv] and x -> max(x, 0)^Ns is monotonic: its value lies between the powers of the
       // two ends (each computed to 14u relative); the midpoint stands for it, half the width is its error
       float plo, phi;
       powi2(fmaxf(rv - drv, 0.0f), rv + drv, ns_loop ? ns_loop : m.ns, &plo, &phi);
       const float spec = 0.5f * (plo + phi);
-      const float espec = 0.5f * (phi - plo) + 16.0f * U * phi;
-      const float ks_r = m.sr * L.sr, ks_g = m.sg * L.sg, ks_b = m.sb * L.sb;
-      r += clamp01f(ks_r * spec); g += clamp01f(ks_g * spec); b += clamp01f(ks_b * spec);  // RTF:259-266
+      const float espec = __builtin_fmaf(0.5f, phi - plo, 16.0f * U * phi);
+      r += clamp01f(m.sr * L.sr * spec); g += clamp01f(m.sg * L.sg * spec); b += clamp01f(m.sb * L.sb * spec);  // RTF:259-266
       const float ksmax = m.smax * L.smax;
       mag += fminf(ksmax * spec, 1.0f);
-      er += ksmax * (espec + 6.0f * U * spec);
+      er = __builtin_fmaf(ksmax, __builtin_fmaf(6.0f * U, spec, espec), er);
     }
   }
-  er += (float)(2 * n_lights + 2) * U * mag;  // the roundings of the additions
-  er += 1.0e-9f * (1.0f + mag);               // the reference's own FP64 roundings, many times over
-  if (flag || !(er < 1.0f)) er = inf;         // (also catches NaN)
+  er = __builtin_fmaf((float)(2 * n_lights + 2) * U, mag, er);  // the roundings of the additions
+  er = __builtin_fmaf(1.0e-9f, 1.0f + mag, er);                 // the reference's own FP64 roundings, many times over
+  if (flag || !(er < 1.0f)) er = inf;                           // (also catches NaN)
   // RTF:269 clamps; a channel whose value is at least 1 whatever the error is exactly 1 in the reference too
   const float cr = clamp01f(r), cg = clamp01f(g), cb = clamp01f(b);
   const float below1 = 1.0f - U;  // the largest float below 1

@@ -106,6 +106,20 @@ def random_case(seed, index):
     return data, cam, params
 
 
+def bounding_spheres_only(data, seed, index):
+    """The scene reduced to what the path without a ray-generation launch serves: only its bounding spheres stay in
+    the list (without materials, up to eight), every specular exponent becomes a small whole number.  None if the scene
+    has no bounding sphere."""
+    rng = np.random.default_rng([seed, index, 7])
+    objs = data.objects[data.objects["kind"] == _abi.RTMI_BOUNDING_SPHERE][:8].copy()
+    if not len(objs):
+        return None
+    objs["material"] = -1
+    mats = data.materials.copy()
+    mats["Ns"] = rng.choice([1.0, 2.0, 8.0, 8.0, 40.0, 64.0], size=len(mats))
+    return scenes.SceneData(lights=data.lights, materials=mats, objects=objs, triangles=data.triangles)
+
+
 def run_one(seed, index, oracle, keep_dir=None, tsan=False):
     from test_emulated_kernels import SEARCHES, check_frames
     data, cam, params = random_case(seed, index)
@@ -115,12 +129,27 @@ def run_one(seed, index, oracle, keep_dir=None, tsan=False):
         params.hit_policy = _abi.RTMI_HIT_NEAREST
     if index % 4 == 1:  # every fourth case with the secondary-ray extensions: distance limit, shadow / reflection rays entering bounding spheres
         params.flags = [2, 4, 6, 8, 12, 14][(index // 4) % 6]
+    # every sixth case asks for pixels only on a scene of bounding spheres: the path without a ray-generation launch (same
+    # bitmap and hit ids as the reference's; the ray counters differ, so they are not compared)
+    pixels_only = index % 6 == 0 and not params.flags and not nearest
+    if pixels_only:
+        reduced = bounding_spheres_only(data, seed, index)
+        pixels_only = reduced is not None
+        if pixels_only:
+            data = reduced
     expected = [oracle.render(data, cam, params, threads=1)] * 2
     env = {"EMU_SEED": str(index % 4), "EMU_FILL": str([0xA5, 0, 0xFF, 0x7F][index % 4]), "EMU_CUS": str(1 + index % 3)}
     if index % 5 == 4:  # candidate lists that overflow, frames cut into batches
         env["RTMI_CAND_CAPACITY"] = str([64, 640, 6400][(index // 5) % 3])
     if index % 7 == 6:
         env["RTMI_MAX_BATCH_SAMPLES"] = "1024"
+    if index % 11 == 3:  # the list of candidates of rays that have several overflows: the decisions scan every candidate
+        env["RTMI_MULTI_CAPACITY"] = "64"
+    if pixels_only:
+        params.flags = _abi.RTMI_FLAG_NO_RAY_STATISTICS
+        expected = [e[:2] + (None,) for e in expected]
+        if index % 12 == 0:
+            env["RTMI_FAST_FORCE"] = str(1 + (index // 12) % 3)
     for name, search in SEARCHES.items():
         if nearest and name != "tree":
             continue

@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 
-from emu_fuzz import random_case  # noqa: E402
+from emu_fuzz import bounding_spheres_only, random_case  # noqa: E402
 from raytracer_amd import _abi, scenes  # noqa: E402
 
 COUNTERS = ("samples", "rays_reflection", "rays_shadow", "sphere_tests", "primary_hits")
@@ -74,6 +74,9 @@ def main(argv=None):
     ap.add_argument("--only", default=None, help="comma-separated case indices")
     ap.add_argument("--meshes", action="store_true", help="closed meshes at top level instead of the emulator fuzzer's soups")
     ap.add_argument("--extras", action="store_true", help="also: a second camera per scene, the pixels-only flag, up to 23 lights")
+    ap.add_argument("--fast", action="store_true",
+                    help="every scene reduced to its bounding spheres (no materials on them, whole-number exponents) and rendered with "
+                         "RTMI_FLAG_NO_RAY_STATISTICS: the path without a ray-generation launch, three frames per scene (two cameras)")
     a = ap.parse_args(argv)
     import oracle
     import raytracer_amd as rt
@@ -89,6 +92,25 @@ def main(argv=None):
             tile = dict(tile_size=params.tile_size, tile_rank=params.tile_rank, tile_world=params.tile_world) if params.tile_world > 1 else {}
             params = scenes.make_params(params.width * a.scale, params.height * a.scale, params.pixel_subdivision, tuple(params.ambient),
                                         window=window, **tile)
+        if a.fast:
+            reduced = bounding_spheres_only(data, a.seed, i)
+            if reduced is None:
+                skipped.append(i)
+                continue
+            _, cam2, _ = random_case(a.seed + 1000, i)
+            want = [oracle.render(reduced, c, params, threads=a.threads) for c in (cam, cam2, cam)]
+            p = copy.copy(params)
+            p.flags = _abi.RTMI_FLAG_NO_RAY_STATISTICS
+            sc = rt.Scene(reduced)
+            try:
+                for k, (c, (o_rgba, o_hit, o_cnt)) in enumerate(zip((cam, cam2, cam), want)):
+                    g_rgba, g_hit, g_cnt = sc.render(c, p)
+                    if not ((g_hit == o_hit).all() and (g_rgba == o_rgba).all() and g_cnt["primary_hits"] == o_cnt["primary_hits"]):
+                        failed.append(i)
+                        print(f"case {i} frame {k} FAILED: {int((g_hit != o_hit).sum())} hit ids, {int((g_rgba != o_rgba).sum())} bytes differ", flush=True)
+            finally:
+                sc.close()
+            continue
         nearest = i % 3 == 2
         if nearest:
             params.hit_policy = _abi.RTMI_HIT_NEAREST

@@ -431,6 +431,7 @@ FAST_CASES = [
     (1, True, (40, 32, 0.5), {}, {"RTMI_FAST_FORCE": "1"}),                   # every pair decided in FP64
     (1, True, (40, 32, 0.5), {}, {"RTMI_FAST_FORCE": "2", "EMU_SEED": "3"}),  # every pixel shaded again in FP64
     (2, True, (36, 30, 0.25), {}, {"RTMI_FAST_FORCE": "3", "RTMI_SEARCH_R": "4"}),
+    (1, True, (40, 32, 0.5), {}, {"RTMI_MULTI_CAPACITY": "64"}),              # the list of candidates of rays with several overflows
 ]
 
 

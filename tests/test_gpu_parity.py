@@ -706,3 +706,12 @@ def test_random_closed_meshes_at_top_level(oracle_mod):
     case 5 to 20 extra lights.  These are the scenes whose bounding-sphere tree has cones of normals."""
     import gpu_fuzz
     assert gpu_fuzz.main(["--cases", "200", "--seed", "61", "--meshes", "--extras"]) == 0
+
+
+def test_random_scenes_of_bounding_spheres_pixels_only(oracle_mod):
+    """The fuzzer's scenes reduced to their bounding spheres and asked for pixels only: the path without a ray-generation
+    launch (FP32 directions, decisions by FP32 margins or in FP64, FP32 lighting with an error bound, FP64 second pass) on
+    cameras inside and outside the geometry, spheres that do not bound, degenerate and non-finite triangles, windows, tiles
+    and every subdivision; two cameras per scene object, frames four times the emulator's size."""
+    import gpu_fuzz
+    assert gpu_fuzz.main(["--cases", "400", "--seed", "71", "--fast", "--scale", "4"]) == 0
