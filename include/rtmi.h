@@ -304,6 +304,15 @@ int32_t rtmi_render_device_noalloc(rtmi_scene* scene, const rtmi_camera* camera,
                                    rtmi_counters* counters);
 int64_t rtmi_noalloc_max_samples(void);
 
+/* Frames of scenes whose list holds nothing but bounding spheres without a material, rendered with
+ * RTMI_FLAG_NO_RAY_STATISTICS, derive their sample directions in FP32 (pixelToWorldCoordinate minus the camera from
+ * per-column and per-row tables, WorldCoordinateSequence.swift:62-66, then a normalisation).  *bound receives the bound the
+ * library assumes on the distance between such a unit direction and the reference's FP64 one for this camera and frame
+ * size -- every FP32 margin of that path is widened by it -- or +infinity if the frame has no usable bound (the general path
+ * renders it then).  Host arithmetic only; exported so that the bound can be checked against observed errors
+ * (tests/test_fast_path_math.py).  No counterpart in the reference, which computes in FP64 throughout. */
+int32_t rtmi_direction_error_bound(const rtmi_camera* camera, int32_t width, int32_t height, double* bound);
+
 /* Orders the scene's stream after work of the caller's: everything enqueued on the scene's stream
  * after this call (the next rtmi_render_begin / rtmi_render_device) starts only when `hip_event`
  * -- a hipEvent_t the caller has recorded on its own stream, on the scene's device -- has

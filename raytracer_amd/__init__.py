@@ -60,6 +60,8 @@ def lib():
         L.rtmi_render_device_noalloc.restype = C.c_int32
         L.rtmi_render_device_noalloc.argtypes = L.rtmi_render_device.argtypes
         L.rtmi_noalloc_max_samples.restype = C.c_int64
+        L.rtmi_direction_error_bound.restype = C.c_int32
+        L.rtmi_direction_error_bound.argtypes = [C.POINTER(Camera), C.c_int32, C.c_int32, C.POINTER(C.c_double)]
         L.rtmi_scene_wait_event.restype = C.c_int32
         L.rtmi_scene_wait_event.argtypes = [C.c_void_p, C.c_void_p]
         L.rtmi_obj_load.restype = C.c_int32
@@ -110,6 +112,13 @@ def bounding_sphere(triangles: np.ndarray):
     tri = np.ascontiguousarray(triangles)
     _check(lib().rtmi_bounding_sphere(tri.ctypes.data, len(tri), c, C.byref(r)), "rtmi_bounding_sphere")
     return tuple(c), r.value
+
+
+def direction_error_bound(camera: Camera, width: int, height: int) -> float:
+    """The bound the pixels-only path assumes on |d - d*| for its FP32 sample directions (rtmi_direction_error_bound)."""
+    b = C.c_double()
+    _check(lib().rtmi_direction_error_bound(C.byref(camera), int(width), int(height), C.byref(b)), "rtmi_direction_error_bound")
+    return b.value
 
 
 def load_obj(obj_path, mtl_path=None):

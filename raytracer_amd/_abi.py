@@ -91,5 +91,5 @@ EXPORTS = [
     "rtmi_obj_load", "rtmi_obj_free", "rtmi_obj_vertex_count", "rtmi_obj_triangle_count", "rtmi_obj_triangles",
     "rtmi_obj_material_count", "rtmi_obj_materials", "rtmi_obj_material_name",
     "rtmi_write_ppm", "rtmi_write_png", "rtmi_tree_slot_order", "rtmi_scene_from_obj",
-    "rtmi_scene_wait_event", "rtmi_render_device_noalloc", "rtmi_noalloc_max_samples",
+    "rtmi_scene_wait_event", "rtmi_render_device_noalloc", "rtmi_noalloc_max_samples", "rtmi_direction_error_bound",
 ]

@@ -96,7 +96,11 @@ struct DevCounters {
   // and with two sets of fill levels like theirs; multi_overflow: a list did not fit (the decisions then scan every candidate)
   int multi_n[2][NSLOT][16];
   int multi_overflow;
-  int pad2[15];
+  // 8x8 pixel blocks of the batch that k_block_cull_compact found live (all of them, also those beyond the list's capacity);
+  // live_overflow: the list did not hold them all -- the frame is incomplete and is rendered again with longer arrays
+  int n_live;
+  int live_overflow;
+  int pad2[13];
 };
 
 struct SceneDev {

@@ -2,7 +2,8 @@
 // The frame of a scene whose top-level list holds nothing but bounding spheres without a material -- what loadObjFile
 // builds (ViewController.swift:101-104) -- when the caller asks for pixels only (RTMI_FLAG_NO_RAY_STATISTICS):
 //
-//   k_block_cull              8x8 pixel blocks none of whose samples can come near a bounding sphere
+//   k_block_cull_compact      the 8x8 pixel blocks some sample of which can come near a bounding sphere: the live blocks.
+//                             Per-sample arrays exist for those only
 //   k_search_tree_fast        per wave of 256 samples: FP32 directions from the sample tables, the cone tree walk;
 //                             emits (sample, list position) candidates, marked when the FP32 edge test is certain
 //   k_search_exact_multi_fast per candidate of a ray that has several: Triangle.intersections in FP64
@@ -38,6 +39,7 @@ __device__ __forceinline__ int fast_first_object(const SceneDev& sc, d3 o, d3 d)
 __global__ void __launch_bounds__(256)
 k_search_exact_multi_fast(const SearchArgs* __restrict__ ap, int parity, FrameConst fc, FastArgs fa) {
   DevCounters* cnt = ap->cnt;
+  fast_live_counts(fa, fc, cnt);
   unsigned int n_exact = 0;
   if (!cnt->overflow) {
     const int list = blockIdx.x & (NSLOT - 1), part = blockIdx.x / NSLOT, parts = gridDim.x / NSLOT;
@@ -92,6 +94,7 @@ k_shade_candidates_fast(FrameConst fc, SceneDev sc, FastArgs fa, const SearchArg
   }
   __syncthreads();
   DevCounters* cnt = (DevCounters*)as_global(ap->cnt);
+  fast_live_counts(fa, fc, cnt);
   unsigned int n_hit = 0, n_exact = 0, n_sure = 0;
   if (!cnt->overflow) {
     const int list = blockIdx.x & (NSLOT - 1), part = blockIdx.x / NSLOT, parts = gridDim.x / NSLOT;
@@ -108,7 +111,7 @@ k_shade_candidates_fast(FrameConst fc, SceneDev sc, FastArgs fa, const SearchArg
     const auto* utab_f = as_global(fc.utab_f);
     const auto* vtab_f = as_global(fc.vtab_f);
     const int n_group = ap->n_group, n_tris = ap->n_tris;
-    const int n_blocks = fa.nsamples / (BLK_PIX * fc.spp);
+    const int n_blocks = max(fa.nsamples / (BLK_PIX * fc.spp), 1);
     const SphereF sph = fa.spheres[fa.obj];
     // what a step needs before anything else: the entry (both indices range-checked, the mark stays on the position), the
     // ray's best position, the sample's block and sub-sample
@@ -208,10 +211,11 @@ k_resolve_fast(FrameConst fc, FastArgs fa, int npix, DevCounters* cnt, unsigned 
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   bool fix = false;
   int x = 0, y = 0;
-  const int b = p >> 6, pix = p & (BLK_PIX - 1);
-  if (p < npix && pixel_coords(fc, fa.blocks, b, pix, &x, &y)) {
+  const int b = p >> 6, pix = p & (BLK_PIX - 1);  // b counts the batch's blocks as the host listed them
+  if (p < npix && pixel_coords(fc, fa.all_blocks, b, pix, &x, &y)) {
     const size_t first_byte = (size_t)4 * fc.W * y + (size_t)x * 4;  // RayTracingFunctions.swift:106-107
-    if (fc.block_live && fc.block_live[b] == 0) {
+    const int slot = fa.block_slot[b];  // among the live blocks: the per-sample arrays are indexed by it
+    if (slot < 0) {
       // no sample of this block can hit anything (k_block_cull): every sample is RGB.black
       *reinterpret_cast<unsigned int*>(rgba + first_byte) = 255u << 24;
       if (hit_out)
@@ -219,7 +223,7 @@ k_resolve_fast(FrameConst fc, FastArgs fa, int npix, DevCounters* cnt, unsigned 
     } else {
       double sr = 0.0, sg = 0.0, sb = 0.0, er = 0.0, eg = 0.0, eb = 0.0;
       for (int q = 0; q < fc.spp; ++q) {
-        const int s = ((b * fc.spp + q) << 6) + pix;
+        const int s = ((slot * fc.spp + q) << 6) + pix;
         const int id = fa.hit_id[s];
         if (id >= 0) {
           const float4 v = fa.rgbf[s];
@@ -279,8 +283,9 @@ k_resolve_fast(FrameConst fc, FastArgs fa, int npix, DevCounters* cnt, unsigned 
 // direction from the tables, the triangle's parameter, calculateLighting (the instantiation without secondary rays)
 // -- then lane 0 adds the colours in sample order as RGB.average does and stores the pixel.
 __global__ void __launch_bounds__(256)
-k_fix_pixels(FrameConst fc, ShadeConst shc, SceneDev sc, FastArgs fa, DevCounters* cnt, unsigned char* rgba) {
+k_fix_pixels(FrameConst fc, ShadeConst shc, SceneDev sc, FastArgs fa, int npix, DevCounters* cnt, unsigned char* rgba) {
   __shared__ double col[4][64][3];
+  fast_live_counts(fa, fc, cnt);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int list = blockIdx.x & (NSLOT - 1), part = blockIdx.x / NSLOT, parts = gridDim.x / NSLOT;
   const int list_cap = fa.fix_cap / NSLOT;
@@ -292,7 +297,9 @@ k_fix_pixels(FrameConst fc, ShadeConst shc, SceneDev sc, FastArgs fa, DevCounter
     const int p = fix[i];
     const int b = p >> 6, pix = p & (BLK_PIX - 1);
     int x, y;
-    if ((unsigned)p >= (unsigned)(fa.nsamples / fc.spp) || !pixel_coords(fc, fa.blocks, b, pix, &x, &y)) {
+    int slot = -1;
+    if ((unsigned)p < (unsigned)npix) slot = fa.block_slot[b];
+    if (slot < 0 || slot >= fa.cap_live || !pixel_coords(fc, fa.all_blocks, b, pix, &x, &y)) {
       cnt->bug = 48;
       continue;
     }
@@ -301,7 +308,7 @@ k_fix_pixels(FrameConst fc, ShadeConst shc, SceneDev sc, FastArgs fa, DevCounter
       const int q = q0 + lane;
       RGBd c = {0.0, 0.0, 0.0};  // RGB.black for a miss
       if (q < fc.spp) {
-        const int s = ((b * fc.spp + q) << 6) + pix;
+        const int s = ((slot * fc.spp + q) << 6) + pix;
         int id = fa.hit_id[s];
         if (id >= 0) {
           id = checked(id, sc.n_tris, cnt, 49);

@@ -22,11 +22,7 @@ constexpr int GEN_ITERS = RTMI_GEN_ITERS;  // samples per thread in k_gen; a wor
 // for the object if cos(theta - phi) stays below the cosine the per-sample pre-test of k_gen demands (whose
 // margin covers the rounding here, FP64, many times over).  A cleared block is never touched by k_gen and
 // written as black by k_resolve.
-__global__ void __launch_bounds__(256)
-k_block_cull(FrameConst fc, const int2* __restrict__ blocks, int nblocks, unsigned char* block_live) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= nblocks) return;
-  const int2 bc = blocks[b];
+__device__ inline bool block_is_live(const FrameConst& fc, int2 bc) {
   const double ic = bc.x * BLK + 0.5 * BLK, jc = bc.y * BLK + 0.5 * BLK;
   const double hu = ic / fc.ppw_h, hv = jc / fc.ppw_v;
   const double dx = (fc.ul[0] - fc.cam[0]) + fc.u[0] * hu - fc.v[0] * hv;
@@ -46,7 +42,55 @@ k_block_cull(FrameConst fc, const int2* __restrict__ blocks, int nblocks, unsign
       live = !(cu < sqrt((double)gf.w));
     }
   }
-  block_live[b] = live ? 1 : 0;
+  return live;
+}
+
+__global__ void __launch_bounds__(256)
+k_block_cull(FrameConst fc, const int2* __restrict__ blocks, int nblocks, unsigned char* block_live) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nblocks) return;
+  block_live[b] = block_is_live(fc, blocks[b]) ? 1 : 0;
+}
+
+// The same test for the frames that run without a ray-generation launch, which keep per-sample arrays for the live
+// blocks only: every live block gets a slot (in no particular order: one atomic per workgroup of 1024) in live_blocks,
+// block_slot[b] is that slot or -1.  Blocks beyond the list's capacity get no slot and raise live_overflow.
+constexpr int CULL_BLOCK = 1024;
+__global__ void __launch_bounds__(CULL_BLOCK)
+k_block_cull_compact(FrameConst fc, const int2* __restrict__ blocks, int nblocks, int2* live_blocks, int* block_slot, int cap_live,
+                     DevCounters* cnt) {
+  __shared__ int wtot[CULL_BLOCK / 64];
+  __shared__ int gbase;
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int2 bc = make_int2(0, 0);
+  bool live = false;
+  if (b < nblocks) {
+    bc = blocks[b];
+    live = block_is_live(fc, bc);
+  }
+  const unsigned long long mask = __ballot(live);
+  if (lane == 0) wtot[w] = __popcll(mask);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tot = 0;
+    for (int q = 0; q < CULL_BLOCK / 64; ++q) tot += wtot[q];
+    gbase = tot ? atomicAdd(&cnt->n_live, tot) : 0;
+  }
+  __syncthreads();
+  if (b >= nblocks) return;
+  int slot = -1;
+  if (live) {
+    slot = gbase + __popcll(mask & ((1ull << lane) - 1ull));
+    for (int q = 0; q < w; ++q) slot += wtot[q];
+    if (slot < cap_live) {
+      live_blocks[slot] = bc;
+    } else {
+      slot = -1;
+      cnt->live_overflow = 1;
+    }
+  }
+  block_slot[b] = slot;
 }
 
 __global__ void __launch_bounds__(256)

@@ -95,8 +95,11 @@ struct SphereF {
 };
 
 struct FastArgs {
-  const int2* blocks;   // the batch's 8x8 pixel blocks
-  int nsamples;         // blocks x 64 x samples per pixel
+  const int2* blocks;   // the batch's LIVE 8x8 pixel blocks (k_block_cull_compact): the per-sample arrays are indexed by them
+  int nsamples;         // live blocks x 64 x samples per pixel; set by each kernel from the device's count (fast_live_counts)
+  int cap_live;         // blocks the live list and the per-sample arrays have room for
+  const int2* all_blocks;  // the batch's blocks as the host listed them, and per such block its slot among the live ones or -1
+  const int* block_slot;
   int obj;              // list index of the bounding sphere whose children this launch searches
   int init_hit;         // this launch writes hit_id = -1 for every rendered sample of the batch (the first group's launch)
   float dir_err;        // bound on |d - d*| for the FP32 directions of fast_dir (host: fast_dir_err)
@@ -113,6 +116,11 @@ struct FastArgs {
   int fix_cap;
   int force;                  // tests: bit 0 = no pair is accepted by the FP32 margins, bit 1 = every pixel goes to k_fix_pixels
 };
+
+// Every kernel of the path starts with this: the number of live blocks is only known on the device.
+__device__ __forceinline__ void fast_live_counts(FastArgs& fa, const FrameConst& fc, const DevCounters* cnt) {
+  fa.nsamples = min(max(cnt->n_live, 0), fa.cap_live) * BLK_PIX * fc.spp;
+}
 
 // The FP32 direction of sub-sample (kx, ky) of pixel (x, y): pixelToWorldCoordinate (WorldCoordinateSequence.swift:62-66)
 // minus the camera, from the FP32 copies of the per-column and per-row tables, normalised with v_rsq_f32.  *f2_out gets
@@ -141,7 +149,8 @@ __device__ __forceinline__ void fast_sample_coords(const FrameConst& fc, const i
 
 // The R rays of a lane in the search without a ray-generation launch.  A sample whose pixel is not rendered, whose
 // block k_block_cull cleared, or whose direction stays clear of the bounding sphere's cone (the pre-test that k_gen
-// applies in the other path, same operands) gets sid = -1 and a NaN direction.  Returns false if the wave has no ray.
+// applies in the other path, same operands) gets sid = -1 and a NaN direction (blocks that k_block_cull_compact cleared
+// are not in the list).  Returns false if the wave has no ray.
 template <int R>
 __device__ __forceinline__ bool fast_prologue(const FrameConst& fc, const FastArgs& fa, DevCounters* cnt, int wave, int lane,
                                               int (&sid)[R], float (&dx)[R], float (&dy)[R], float (&dz)[R]) {
@@ -156,7 +165,6 @@ __device__ __forceinline__ bool fast_prologue(const FrameConst& fc, const FastAr
     if ((t << 6) >= fa.nsamples) continue;
     int b, kx, ky;
     group_coords(fc, t, &b, &kx, &ky);
-    if (fc.block_live && fc.block_live[b] == 0) continue;  // wave-uniform
     int x, y;
     if (!pixel_coords(fc, fa.blocks, b, lane, &x, &y)) continue;
     const int s = (t << 6) + lane;
@@ -203,12 +211,11 @@ __device__ __forceinline__ void multi_flush(const SearchArgs* ap, const int2* ms
 template <int R, bool FAST>
 __device__ __forceinline__ void search_tree_body(const SearchArgs* __restrict__ ap, const f2* __restrict__ rec,
                                                  const float* __restrict__ edge_all, const int* __restrict__ slot_pos, int parity,
-                                                 const FrameConst* fcp, const FastArgs* fap) {
+                                                 const FrameConst* fcp, const FastArgs* fap, int wave) {
   __shared__ int2 stage_all[4][CAND_STAGE];
   __shared__ int2 mstage_all[4][MULTI_STAGE];
   const int nq = FAST ? fap->nsamples : *ap->nq_ptr;
   const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int base = wave * 64 * R;
   if (base >= nq) return;  // no workgroup-wide synchronisation below: waves leave on their own
   int2* stage = stage_all[threadIdx.x >> 6];
@@ -387,18 +394,25 @@ __device__ __forceinline__ void search_tree_body(const SearchArgs* __restrict__ 
   if constexpr (FAST) wave_count(cnt, C_PRIMARY_TRACED, lane == 0 ? (unsigned long long)active : 0ull);
 }
 
+#ifndef RTMI_TREE_WAVES
+#define RTMI_TREE_WAVES 7
+#endif
 template <int R>
-__global__ void __launch_bounds__(256, R <= 4 ? 7 : 6)
+__global__ void __launch_bounds__(256, R <= 4 ? RTMI_TREE_WAVES : 6)
 k_search_tree(const SearchArgs* __restrict__ ap, const f2* __restrict__ rec, const float* __restrict__ edge_all,
               const int* __restrict__ slot_pos, int parity) {
-  search_tree_body<R, false>(ap, rec, edge_all, slot_pos, parity, nullptr, nullptr);
+  search_tree_body<R, false>(ap, rec, edge_all, slot_pos, parity, nullptr, nullptr, (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
 }
 
 template <int R>
-__global__ void __launch_bounds__(256, R <= 4 ? 7 : 6)
+__global__ void __launch_bounds__(256, R <= 4 ? RTMI_TREE_WAVES : 6)
 k_search_tree_fast(const SearchArgs* __restrict__ ap, const f2* __restrict__ rec, const float* __restrict__ edge_all,
                    const int* __restrict__ slot_pos, int parity, FrameConst fc, FastArgs fa) {
-  search_tree_body<R, true>(ap, rec, edge_all, slot_pos, parity, &fc, &fa);
+  // The grid covers the samples the per-sample arrays have room for; how many of them exist only the device knows, and the
+  // waves beyond them leave at once.  (A grid of resident workgroups that loop over the groups of samples was measured
+  // 5 to 20 % slower: the hardware's own dispatch balances waves of unequal work better than a fixed stride does.)
+  fast_live_counts(fa, fc, ap->cnt);
+  search_tree_body<R, true>(ap, rec, edge_all, slot_pos, parity, &fc, &fa, (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
 }
 
 // One lane per candidate: the reference's own arithmetic in FP64; a hit competes for the ray's

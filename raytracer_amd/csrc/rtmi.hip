@@ -143,6 +143,11 @@ struct FastBufs {
   size_t cap_multi = 0;
   int* fix_list = nullptr;   // pixels for k_fix_pixels
   size_t cap_fix = 0;
+  int2* live_blocks = nullptr;  // the batch's live 8x8 blocks (k_block_cull_compact); cap_samples = cap_live x 64 x spp
+  size_t cap_live = 0;          // blocks
+  int* block_slot = nullptr;    // per block of the host's list: slot among the live ones, or -1
+  size_t cap_slots = 0;
+  size_t live_wanted = 0;       // blocks: what the arrays are grown to when a frame last overflowed them
   unsigned char* consts = nullptr;  // per frame: LightF per light, MatF per material, SphereF per object
   size_t cap_consts = 0;
   std::vector<unsigned char> consts_uploaded;  // what `consts` holds (the async copy reads it after the call returns)
@@ -312,6 +317,7 @@ struct rtmi_scene {
   long long pend_launches = 0;
   int64_t pend_live_samples = 0;
   bool pend_shade_timed = false;
+  bool pend_fast = false;  // the frame in flight runs without a ray-generation launch
   rtmi_camera pend_cam{};
   rtmi_params pend_params{};
   void* pend_rgba = nullptr;
@@ -475,7 +481,7 @@ extern "C" void rtmi_scene_destroy(rtmi_scene* sc) {
     (void)hipFree(g.d_nodes); (void)hipFree(g.d_ticket); (void)hipFree(g.d_pos_plane); (void)hipFree(g.d_pos_mt);
   }
   (void)hipFree(sc->fast.hit_id); (void)hipFree(sc->fast.best_pos); (void)hipFree(sc->fast.rgbf); (void)hipFree(sc->fast.cand);
-  (void)hipFree(sc->fast.multi); (void)hipFree(sc->wb.multi);
+  (void)hipFree(sc->fast.multi); (void)hipFree(sc->wb.multi); (void)hipFree(sc->fast.live_blocks); (void)hipFree(sc->fast.block_slot);
   (void)hipFree(sc->fast.fix_list); (void)hipFree(sc->fast.consts);
   (void)hipFree(sc->d_objects); (void)hipFree(sc->d_lights); (void)hipFree(sc->d_materials);
   (void)hipFree(sc->d_tris); (void)hipFree(sc->d_planes); (void)hipFree(sc->d_tri_owner);
@@ -914,6 +920,27 @@ static size_t max_batch_samples() {
   return v;
 }
 
+// The camera frame: RayTracingFunctions.swift:156-170 (focal-plane centre, the fixed 10 x 10 window, its corners) and
+// WorldCoordinateSequence.swift:58-59 (pixels per world unit from the frame's last pixel index).
+static void frame_basis(const rtmi_camera* cam, int width, int height, FrameConst* fc) {
+  d3 camera = rtx::ld3(cam->pos);
+  d3 center = rtx::add(camera, rtx::smul(cam->focal_length, rtx::ld3(cam->dir)));
+  d3 u, v;
+  rtx::plane_vectors(rtx::ld3(cam->dir), &u, &v);
+  d3 hpc = rtx::muls(u, 10.0 / 2.0), vpc = rtx::muls(v, 10.0 / 2.0);
+  d3 ul = rtx::add(rtx::sub(center, hpc), vpc);
+  d3 ur = rtx::add(rtx::add(center, hpc), vpc);
+  d3 ll = rtx::sub(rtx::sub(center, hpc), vpc);
+  fc->ul[0] = ul.x; fc->ul[1] = ul.y; fc->ul[2] = ul.z;
+  fc->u[0] = u.x; fc->u[1] = u.y; fc->u[2] = u.z;
+  fc->v[0] = v.x; fc->v[1] = v.y; fc->v[2] = v.z;
+  fc->cam[0] = camera.x; fc->cam[1] = camera.y; fc->cam[2] = camera.z;
+  fc->ppw_h = (double)(width - 1) / sqrt(rtx::len_squared(rtx::sub(ur, ul)));
+  fc->ppw_v = (double)(height - 1) / sqrt(rtx::len_squared(rtx::sub(ll, ul)));
+  fc->W = width;
+  fc->H = height;
+}
+
 // RTMI_FAST=0: frames that qualify for the path without a ray-generation launch take the general path (for comparison).
 static bool fast_enabled() {
   static bool v = [] {
@@ -959,10 +986,15 @@ static double fast_dir_err(const FrameConst& fc, const rtmi_camera* cam) {
   return std::isfinite(err) && dmin > 0 ? err : INFINITY;
 }
 
-static int32_t ensure_fast_buffers(rtmi_scene* sc, size_t samples, size_t pixels, size_t consts_bytes) {
+// live_blocks: the 8x8 blocks (of one batch) the per-sample arrays must have room for; all_blocks: blocks of the largest batch.
+static int32_t ensure_fast_buffers(rtmi_scene* sc, size_t live_blocks, size_t samples_per_block, size_t all_blocks, size_t consts_bytes) {
   FastBufs& f = sc->fast;
-  if (samples > f.cap_samples) {
+  const size_t samples = live_blocks * samples_per_block;
+  if (samples > f.cap_samples || live_blocks > f.cap_live) {
     (void)hipFree(f.hit_id); (void)hipFree(f.best_pos); (void)hipFree(f.rgbf); (void)hipFree(f.cand); (void)hipFree(f.multi);
+    (void)hipFree(f.live_blocks);
+    f.live_blocks = nullptr;
+    f.cap_live = 0;
     f.multi = nullptr;
     f.cap_multi = 0;
     f.hit_id = f.best_pos = nullptr;
@@ -984,9 +1016,19 @@ static int32_t ensure_fast_buffers(rtmi_scene* sc, size_t samples, size_t pixels
       if (v > 0) f.cap_multi = (size_t)std::max<long long>(v, NSLOT);
     }
     HIP_TRY(hipMalloc(&f.multi, sizeof(int2) * f.cap_multi));
+    HIP_TRY(hipMalloc(&f.live_blocks, sizeof(int2) * live_blocks));
+    f.cap_live = live_blocks;
     f.cap_samples = samples;
   }
+  if (all_blocks > f.cap_slots) {
+    (void)hipFree(f.block_slot);
+    f.block_slot = nullptr;
+    f.cap_slots = 0;
+    HIP_TRY(hipMalloc(&f.block_slot, sizeof(int) * all_blocks));
+    f.cap_slots = all_blocks;
+  }
   // a list of k_resolve_fast holds every pixel of the workgroups that append to it
+  const size_t pixels = all_blocks * BLK_PIX;
   const size_t fix = ((pixels + 255) / 256 + NSLOT - 1) / NSLOT * 256 * NSLOT;
   if (fix > f.cap_fix) {
     (void)hipFree(f.fix_list);
@@ -1004,6 +1046,19 @@ static int32_t ensure_fast_buffers(rtmi_scene* sc, size_t samples, size_t pixels
     f.cap_consts = consts_bytes;
   }
   return RTMI_OK;
+}
+
+// Blocks the live list of a batch of `batch_blocks` gets room for.  Half of them to start with (a mesh wrapped in its
+// bounding sphere rarely fills the frame), all of them for small frames; a frame that needs more is rendered again with
+// what it needed and a quarter on top (render_finish), and the scene keeps that.  RTMI_LIVE_CAPACITY (tests) sets the start.
+static size_t fast_live_capacity(const rtmi_scene* sc, size_t batch_blocks) {
+  size_t want = batch_blocks <= 4096 ? batch_blocks : std::max<size_t>(4096, batch_blocks / 2);
+  if (const char* e = getenv("RTMI_LIVE_CAPACITY")) {
+    const long long v = atoll(e);
+    if (v > 0) want = (size_t)v;
+  }
+  want = std::max(want, sc->fast.live_wanted);
+  return std::max<size_t>(1, std::min(want, batch_blocks));
 }
 
 // Enqueue a whole frame on the scene's stream; nothing here waits for the device.  The caller
@@ -1084,22 +1139,7 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
 
   // camera frame: RayTracingFunctions.swift:156-170, WorldCoordinateSequence.swift:58-59
   FrameConst fc{};
-  {
-    d3 camera = rtx::ld3(cam->pos);
-    d3 center = rtx::add(camera, rtx::smul(cam->focal_length, rtx::ld3(cam->dir)));
-    d3 u, v;
-    rtx::plane_vectors(rtx::ld3(cam->dir), &u, &v);
-    d3 hpc = rtx::muls(u, 10.0 / 2.0), vpc = rtx::muls(v, 10.0 / 2.0);
-    d3 ul = rtx::add(rtx::sub(center, hpc), vpc);
-    d3 ur = rtx::add(rtx::add(center, hpc), vpc);
-    d3 ll = rtx::sub(rtx::sub(center, hpc), vpc);
-    fc.ul[0] = ul.x; fc.ul[1] = ul.y; fc.ul[2] = ul.z;
-    fc.u[0] = u.x; fc.u[1] = u.y; fc.u[2] = u.z;
-    fc.v[0] = v.x; fc.v[1] = v.y; fc.v[2] = v.z;
-    fc.cam[0] = camera.x; fc.cam[1] = camera.y; fc.cam[2] = camera.z;
-    fc.ppw_h = (double)(p->width - 1) / sqrt(rtx::len_squared(rtx::sub(ur, ul)));
-    fc.ppw_v = (double)(p->height - 1) / sqrt(rtx::len_squared(rtx::sub(ll, ul)));
-  }
+  frame_basis(cam, p->width, p->height, &fc);
   fc.nearest = nearest ? 1 : 0;
   fc.sub = p->pixel_subdivision;
   for (int a = 0; a < 3; ++a) fc.ambient[a] = p->ambient[a];
@@ -1239,7 +1279,7 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
   if (fast) {
     const size_t consts_bytes = sizeof(rtx32::LightF) * std::max(1, sc->n_lights) + sizeof(rtx32::MatF) * std::max(1, sc->n_materials) +
                                 sizeof(SphereF) * sc->objects.size();
-    rc = ensure_fast_buffers(sc, max_batch_blocks * samples_per_block, max_batch_blocks * BLK_PIX, consts_bytes);
+    rc = ensure_fast_buffers(sc, fast_live_capacity(sc, max_batch_blocks), samples_per_block, max_batch_blocks, consts_bytes);
     if (rc) return rc;
     // the frame's constants for the FP32 lighting and the FP32 sphere test: FP64 differences and products, rounded once
     std::vector<unsigned char> cb(consts_bytes, 0);
@@ -1289,6 +1329,9 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
     fa.lights = reinterpret_cast<const rtx32::LightF*>(sc->fast.consts);
     fa.mats = reinterpret_cast<const rtx32::MatF*>(sc->fast.consts + (reinterpret_cast<unsigned char*>(mf) - cb.data()));
     fa.spheres = reinterpret_cast<const SphereF*>(sc->fast.consts + (reinterpret_cast<unsigned char*>(sf) - cb.data()));
+    fa.cap_live = (int)std::min<size_t>(sc->fast.cap_samples / samples_per_block, std::min<size_t>(sc->fast.cap_live, 0x7fffffff / samples_per_block));
+    fa.blocks = sc->fast.live_blocks;
+    fa.block_slot = sc->fast.block_slot;
     fa.fix_list = sc->fast.fix_list;
     fa.fix_cap = (int)std::min<size_t>(sc->fast.cap_fix, 0x7fffffff);
     fa.force = fast_force();
@@ -1309,7 +1352,7 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
   // blocks none of whose samples can come near any object (same operands as k_gen's pre-test): every frame,
   // the test is one thread per block
   fc.block_live = nullptr;
-  if (fc.n_genf > 0 && !blocks.empty()) {
+  if (fc.n_genf > 0 && !blocks.empty() && !fast) {  // (the other path culls and compacts batch by batch)
     hipLaunchKernelGGL(k_block_cull, dim3((unsigned)((blocks.size() + 255) / 256)), dim3(256), 0, st, fc,
                        (const int2*)sc->wb.blocks, (int)blocks.size(), sc->wb.block_live);
     fc.block_live = sc->wb.block_live;
@@ -1417,11 +1460,18 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
     int grid = (nsamples + 255) / 256;
     if (fast) {
       const int SRf = search_rays_per_lane(true, nsamples);
-      const int fgrid = (nsamples + 256 * SRf - 1) / (256 * SRf);
+      // one wave per group of R x 64 samples that the arrays have room for (the live blocks are at most that many)
+      const long long room = std::min<long long>((long long)fa.cap_live * (long long)samples_per_block, nsamples);
+      const int fgrid = (int)std::max<long long>(1, (room + 256 * SRf - 1) / (256 * SRf));
       auto tree_fast = SRf == 8 ? k_search_tree_fast<8> : (SRf == 2 ? k_search_tree_fast<2> : k_search_tree_fast<4>);
-      fa.blocks = d_blk;
-      fa.nsamples = nsamples;
-      if (b0 > 0) HIP_TRY(hipMemsetAsync(&sc->wb.cnt->fix_n[0][0], 0, sizeof(sc->wb.cnt->fix_n), st));
+      fa.all_blocks = d_blk;
+      fa.nsamples = 0;  // the kernels read the live count from the device
+      if (b0 > 0) {
+        HIP_TRY(hipMemsetAsync(&sc->wb.cnt->fix_n[0][0], 0, sizeof(sc->wb.cnt->fix_n), st));
+        HIP_TRY(hipMemsetAsync(&sc->wb.cnt->n_live, 0, sizeof(int), st));
+      }
+      hipLaunchKernelGGL(k_block_cull_compact, dim3((unsigned)((nb + CULL_BLOCK - 1) / CULL_BLOCK)), dim3(CULL_BLOCK), 0, st, fcb, d_blk, (int)nb,
+                         sc->fast.live_blocks, sc->fast.block_slot, fa.cap_live, sc->wb.cnt);
       for (size_t gi = 1; gi < sc->groups.size(); ++gi) {
         TriGroup& g = sc->groups[gi];
         hipEvent_t* ev;
@@ -1444,7 +1494,7 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
       const int npix_f = (int)(nb * BLK_PIX);
       hipLaunchKernelGGL(k_resolve_fast, dim3((npix_f + 255) / 256), dim3(256), 0, st, fcb, fa, npix_f, sc->wb.cnt, (unsigned char*)rgba_dev,
                          (int*)hit_dev);
-      hipLaunchKernelGGL(k_fix_pixels, dim3(sc->exact_grid), dim3(256), 0, st, fcb, shc, sc->dev, fa, sc->wb.cnt, (unsigned char*)rgba_dev);
+      hipLaunchKernelGGL(k_fix_pixels, dim3(sc->exact_grid), dim3(256), 0, st, fcb, shc, sc->dev, fa, npix_f, sc->wb.cnt, (unsigned char*)rgba_dev);
       HIP_TRY(hipGetLastError());
       continue;
     }
@@ -1584,6 +1634,7 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
   sc->pend_launches = launches;
   sc->pend_live_samples = live_samples;
   sc->pend_shade_timed = shade_queue_launched;
+  sc->pend_fast = fast;
   sc->pend_cam = *cam;
   sc->pend_params = *p;
   sc->pend_rgba = rgba_dev;
@@ -1608,6 +1659,22 @@ static int32_t render_finish(rtmi_scene* sc, rtmi_counters* counters) {
   sc->pending = false;
   HIP_TRY(hipSetDevice(sc->device));
   HIP_TRY(hipStreamSynchronize(sc->stream));
+  // More live 8x8 blocks than the per-sample arrays of the path without a ray-generation launch have room for: the
+  // frame is rendered again with arrays for what it needed and a quarter on top (the count is exact for a frame of one batch).
+  for (int attempt = 0; sc->pend_fast && sc->h_cnt->live_overflow; ++attempt) {
+    const size_t had = sc->fast.cap_live;
+    sc->fast.live_wanted = std::max<size_t>(had * 2, (size_t)std::max(sc->h_cnt->n_live, 0) * 5 / 4 + 1);
+    if (attempt == 8) {
+      g_last_error = "the live-block list kept overflowing";
+      return RTMI_ERR_HIP;
+    }
+    const rtmi_camera cam2 = sc->pend_cam;
+    const rtmi_params p2 = sc->pend_params;
+    int32_t rc = render_enqueue(sc, &cam2, &p2, sc->pend_rgba, sc->pend_hit);
+    if (rc != RTMI_OK) return rc;
+    sc->pending = false;
+    HIP_TRY(hipStreamSynchronize(sc->stream));
+  }
   if (sc->h_cnt->overflow && sc->pend_params.search == RTMI_SEARCH_CONE_TREE) {
     // More candidate pairs than the list holds (rays that pass very many triangle cones, e.g. deep
     // stacks of overlapping triangles): the frame is rendered again with the list scan, which
@@ -1774,6 +1841,14 @@ extern "C" int32_t rtmi_render_device_noalloc(rtmi_scene* sc, const rtmi_camera*
 }
 
 extern "C" int64_t rtmi_noalloc_max_samples(void) { return (int64_t)NOALLOC_MAX_SAMPLES; }
+
+extern "C" int32_t rtmi_direction_error_bound(const rtmi_camera* cam, int32_t width, int32_t height, double* bound) {
+  if (!cam || !bound || width < 2 || height < 2 || width > MAX_FRAME_EDGE || height > MAX_FRAME_EDGE) return RTMI_ERR_INVALID_ARGUMENT;
+  FrameConst fc{};
+  frame_basis(cam, width, height, &fc);
+  *bound = fast_dir_err(fc, cam);
+  return RTMI_OK;
+}
 
 // Work enqueued on the scene's stream after this call starts only when `hip_event` has completed.
 extern "C" int32_t rtmi_scene_wait_event(rtmi_scene* sc, void* hip_event) {

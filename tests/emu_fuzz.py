@@ -143,6 +143,8 @@ def run_one(seed, index, oracle, keep_dir=None, tsan=False):
         env["RTMI_CAND_CAPACITY"] = str([64, 640, 6400][(index // 5) % 3])
     if index % 7 == 6:
         env["RTMI_MAX_BATCH_SAMPLES"] = "1024"
+    if index % 9 == 6:  # room for two live 8x8 blocks to start with: frames that need more are rendered again
+        env["RTMI_LIVE_CAPACITY"] = "2"
     if index % 11 == 3:  # the list of candidates of rays that have several overflows: the decisions scan every candidate
         env["RTMI_MULTI_CAPACITY"] = "64"
     if pixels_only:

@@ -66,7 +66,7 @@ TSAN_BIN = os.path.join(EMU_DIR, "build_tsan", "emu_render")
 CSRC = os.path.join(HERE, "..", "raytracer_amd", "csrc")
 # Stores that several work-items may make at once ON PURPOSE: all of them store the same value (a flag that only
 # ever goes from 0 to nonzero), and it is read after the kernel has ended.
-BENIGN_RACY_STORES = ("cnt->overflow = 1", "cnt->multi_overflow = 1", "cnt->bug = code", "ap->cnt->bug = ", "CONE_FLAG] = 1")
+BENIGN_RACY_STORES = ("cnt->overflow = 1", "cnt->multi_overflow = 1", "cnt->live_overflow = 1", "cnt->bug = code", "ap->cnt->bug = ", "CONE_FLAG] = 1")
 
 
 def race_reports(stderr):

@@ -432,6 +432,8 @@ FAST_CASES = [
     (1, True, (40, 32, 0.5), {}, {"RTMI_FAST_FORCE": "2", "EMU_SEED": "3"}),  # every pixel shaded again in FP64
     (2, True, (36, 30, 0.25), {}, {"RTMI_FAST_FORCE": "3", "RTMI_SEARCH_R": "4"}),
     (1, True, (40, 32, 0.5), {}, {"RTMI_MULTI_CAPACITY": "64"}),              # the list of candidates of rays with several overflows
+    (1, True, (72, 56, 0.5), {}, {"RTMI_LIVE_CAPACITY": "3"}),                # more live blocks than the arrays hold: rendered again with more
+    (2, False, (64, 48, 0.25), {}, {"RTMI_LIVE_CAPACITY": "2", "RTMI_MAX_BATCH_SAMPLES": "8192", "EMU_CUS": "1"}),
 ]
 
 
