@@ -5,11 +5,18 @@ A step is one full frame of the headline configuration: the stand-in "pig" mesh 
 wrapped in Sphere(boundingObjects:), i.e. form B, what the reference's loadObjFile builds), 3840x2160, 16 samples per
 pixel (pixelSubdivision 0.25), 3 lights, reference-exact list-order hit policy, the camera moving every step on the
 orbit of config 5 (--static-camera holds it still).  Timed frames ask for pixels only (RTMI_FLAG_NO_RAY_STATISTICS):
-rays that cannot change a pixel are neither traced nor counted.  With N > 1 the frame's 32x32 tiles are dealt
-cyclically over the ranks (strong scaling: total work per step is fixed), the scene is broadcast once over RCCL before
-the timed region and every rank's own pixels are gathered on rank 0 inside it.
+rays that cannot change a pixel are neither traced nor counted.
 
-`value` = rays actually traced per second (primary rays that were generated and tested + reflection and shadow rays
+  python bench.py --gpus N            C3: with N > 1 the frame's 32x32 tiles are dealt cyclically over the ranks (strong
+                                      scaling: total work per step is fixed), the scene is broadcast once over RCCL before
+                                      the timed region and every rank's own pixels are gathered on rank 0 inside it
+  python bench.py --gpus N --config C5   a batch of orbit frames: one WHOLE frame per step, frame i on rank i mod N, two in
+                                      flight per rank, no collective in the timed region (digests gathered after it)
+
+Without a launcher around it (`WORLD_SIZE` unset) `--gpus N` starts its N ranks itself: torch.distributed.run as a
+child process, before this process has touched a GPU.
+
+`value` = rays actually traced per second (primary rays that were generated and searched + reflection and shadow rays
 that were traced); the count of rays the REFERENCE traces for the same frames is reported beside it
 (`reference_rays`), taken from an extra frame with full ray statistics after the timed region.
 
@@ -30,7 +37,7 @@ PEAK_FP32_TFLOPS = 157.3       # MI355X vector FP32, packed (256 CU x 4 SIMD x 6
 PEAK_FP64_TFLOPS = 78.6        # MI355X vector FP64 (256 CU x 4 SIMD x 32 FLOP/clk x 2.4 GHz)
 PEAK_HBM_GBPS = 8000.0         # MI355X HBM3E
 SIMDS = 1024                   # 256 CUs x 4
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_kernels.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_kernels.json")
 
 CONFIGS = {
     # name: (width, height, subdivision, mesh level, n_lights)
@@ -269,8 +276,9 @@ def run_tiled_frames(args, rtm):
 
     keys = ("samples", "primary_rays_traced", "rays_reflection", "rays_shadow", "shadow_rays_elided", "tri_tests",
             "tri_tests_primary_kernel", "ms_primary_kernel", "ms_total", "tri_search_launches", "tri_exact_tests", "primary_hits",
-            "ms_shade", "node_tests", "tri_candidates")
+            "ms_shade", "node_tests", "tri_candidates", "hits_decided_fp32", "pixels_fixed_fp64", "tri_edge_tests")
     totals = {k: 0 for k in keys}
+    work_bytes = [0]
     host = {"enqueue_s": 0.0, "wait_s": 0.0, "compose_s": 0.0}
 
     # With more than one rank a frame is short (1/N of the work) and the gaps between frames start to show: each
@@ -292,6 +300,7 @@ def run_tiled_frames(args, rtm):
         if record_:
             for k in keys:
                 totals[k] += cnt[k]
+            work_bytes[0] = max(work_bytes[0], cnt["work_buffer_bytes"])
             host["wait_s"] += t1 - t0
             host["compose_s"] += t2 - t1
 
@@ -367,16 +376,18 @@ def run_tiled_frames(args, rtm):
         ms_step = elapsed_max / steps * 1e3
         ref = aux.get("reference_counts")
         inert = args.form == "B" and not args.ray_stats and args.search == "tree"
-        roofline = shade_roofline(args, totals, steps, n_lights, inert) if args.search == "tree" else \
+        fast = totals["hits_decided_fp32"] > 0  # the path without a ray-generation launch ran (kernels_fast.h)
+        roofline = (walk_roofline(args, totals, steps) if fast else shade_roofline(args, totals, steps, n_lights, inert)) if args.search == "tree" else \
             scan_roofline(totals["tri_tests_primary_kernel"] / max(totals["tri_search_launches"], 1),
                           totals["ms_primary_kernel"] / max(totals["tri_search_launches"], 1), args.config)
         out = {
             "metric": "Mrays/s + ray-tri tests/s (% FP32 peak), pig OBJ 4K 16spp, 1/2/4/8 GPU",
             "value": round(total_traced / elapsed_max / 1e6, 3),
             "unit": "Mrays/s",
-            "value_note": "rays actually traced per second: primary rays that were generated and tested with the reference's "
-                          "arithmetic, plus the reflection and shadow rays that were traced.  Samples cleared beforehand by a "
-                          "conservative test and rays whose outcome cannot change a pixel are not counted.",
+            "value_note": "rays actually traced per second: primary rays that were generated and went on to the triangle search, "
+                          "plus the reflection and shadow rays that were traced.  Samples cleared beforehand by a "
+                          "conservative test (whole 8x8 blocks, then single samples against the bounding sphere's cone) and rays "
+                          "whose outcome cannot change a pixel are not counted.",
             "n_gpus": world,
             "steps": steps,
             "warmup": args.warmup,
@@ -385,8 +396,11 @@ def run_tiled_frames(args, rtm):
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f64",
-            "dtype_note": "every decision (ray generation, sphere and triangle tests, shading) is FP64 in the reference's operation "
-                          "order; FP32 is used only by conservative filters that nominate (ray, triangle) pairs",
+            "dtype_note": "the reference computes in FP64 and so does every decision here that FP32 cannot make with certainty: FP32 "
+                          "filters nominate (ray, triangle) pairs, FP32 margins accept the pairs that are inside triangle and bounding "
+                          "sphere beyond the FP32 error, the others are decided in FP64 in the reference's operation order; colours "
+                          "are FP32 with an error bound, and the pixels whose byte that bound cannot settle are shaded again in FP64 "
+                          "(see fp32_first)",
             "data": "synthetic",
             "config": {
                 "workload": f"{args.config}: pig mesh [{mesh_note}; default = displaced icosphere level {level}], "
@@ -429,6 +443,17 @@ def run_tiled_frames(args, rtm):
                                       "candidates": totals["tri_candidates"] // steps,
                                       "fp64_decisions": totals["tri_exact_tests"] // steps,
                                       "primary_hits": totals["primary_hits"] // steps},
+            "fp32_first": None if not fast else {
+                "hits_decided_by_fp32_margins": totals["hits_decided_fp32"] // steps,
+                "pairs_decided_in_fp64": totals["tri_exact_tests"] // steps,
+                "share_of_hits_decided_in_fp32": round(totals["hits_decided_fp32"] / max(totals["primary_hits"], 1), 5),
+                "pixels_shaded_again_in_fp64": totals["pixels_fixed_fp64"] // steps,
+                "share_of_hit_pixels_shaded_again": round(totals["pixels_fixed_fp64"] / max(totals["primary_hits"] / scene_spp(sub), 1), 5),
+                "note": "rank 0, per step.  A hit is accepted by FP32 alone when the ray lies inside the triangle's three edge planes, "
+                        "in front of its plane and inside the bounding sphere by margins above the FP32 error (bound on the "
+                        "directions: rtmi_direction_error_bound); a pixel is shaded again when a sample's light faces the surface "
+                        "within the error, or 255 x mean +- the summed error bound of its samples holds a whole number"},
+            "work_buffer_bytes_rank0": work_bytes[0],
             "device_ms_per_step_rank0": round(totals["ms_total"] / steps, 4),
             "per_rank": [{"rank": r, "device_ms_per_step": round(v[3], 4), "wall_ms_per_step": round(v[2] / steps * 1e3, 4),
                           "host_enqueue_ms": round(v[4], 4), "host_wait_ms": round(v[5], 4), "host_compose_enqueue_ms": round(v[6], 4)}
@@ -630,6 +655,39 @@ def run_orbit_batch(args, rtm):
         print(json.dumps(out_line), flush=True)
     for sc_ in renderers:
         sc_.close()
+
+
+def walk_roofline(args, totals, steps):
+    """The dominant kernel of the pixels-only frame: the cone tree walk with FP32 ray generation (FP32 VALU)."""
+    ms = totals["ms_primary_kernel"] / max(totals["tri_search_launches"], 1)
+    node, tri, edge = (totals[k] / steps for k in ("node_tests", "tri_tests_primary_kernel", "tri_edge_tests"))
+    traced = totals["primary_rays_traced"] / steps
+    flops = 6.0 * (node + tri) + 18.0 * edge + 18.0 * traced
+    achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    kernel = "k_search_tree_fast<4>"
+    pmc = pmc_fractions(pmc_kernel(args.config, kernel))
+    return {
+        "bound": "valu_fp32",
+        "kernel": kernel,
+        "achieved": round(achieved, 3),
+        "peak": PEAK_FP32_TFLOPS,
+        "unit": "TFLOP/s",
+        "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
+        "traffic": pmc.get("hbm_bytes_per_launch") if pmc else None,
+        "traffic_unit": "bytes of HBM traffic per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes; "
+                        + os.path.relpath(PMC_FILE, ROOT) + ")",
+        "algorithmic_flops_per_launch": flops,
+        "algorithmic_bytes_per_launch": 8.0 * traced + 8.0 * totals["tri_candidates"] / steps,
+        "work_per_launch": {"ray_node_cone_tests": node, "ray_triangle_cone_tests": tri, "ray_triangle_edge_tests": edge, "rays": traced},
+        "avg_launch_ms": round(ms, 4),
+        "executed": pmc,
+        "note": "achieved = the FP32 operations the launch has to perform -- 3 fused multiply-adds (6 flops) per (ray, node) and per "
+                "(ray, triangle) cone test, 9 (18 flops) per (ray, triangle) edge test, 18 flops per ray for its direction -- / launch "
+                "time (HIP events on the library's stream around this kernel alone).  The walk itself (which records a wave "
+                "visits) is scalar code and is not counted.  peak = packed FP32 (two cone tests per v_pk_fma_f32); the edge test "
+                "is unpacked.  algorithmic_bytes = what must cross HBM: 8 B per ray that is searched (best position and hit id "
+                "initialised) + 8 B per candidate written.  `executed` holds what the hardware did according to the PMC counters.",
+    }
 
 
 def shade_roofline(args, totals, steps, n_lights, inert):

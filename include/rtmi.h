@@ -197,7 +197,8 @@ typedef struct {
                                FP64 decision; list scan: the scan kernel)                */
   int64_t tri_search_launches;
   int64_t tri_tests_primary_kernel; /* pairs evaluated by the common-origin kernel       */
-  double ms_primary_kernel; /* its accumulated launch time                               */
+  double ms_primary_kernel; /* accumulated launch time of that kernel alone: the list scan, or the cone tree's
+                               walk (k_search_tree) without the FP64 decisions that follow it */
   double ms_shade;          /* device time of the shading launches                       */
   int64_t primary_rays_traced; /* of samples: those whose ray was generated and went on to the sphere tests and the
                                   triangle search; the rest were cleared beforehand by a conservative test that
@@ -209,6 +210,10 @@ typedef struct {
   int64_t pixels_fixed_fp64;   /* the same frames: pixels whose bytes the FP32 lighting and its error bound could not
                                   settle; every sample of such a pixel was shaded again with the reference's FP64
                                   arithmetic                                                          */
+  int64_t tri_edge_tests;      /* cone tree only: (ray, triangle) pairs that went through the FP32 edge test (the
+                                  lanes of a wave evaluate it together for a triangle whose cone some ray of theirs passes) */
+  int64_t work_buffer_bytes;   /* device memory of the per-frame work buffers (per-sample arrays, candidate lists, tables,
+                                  block lists) the scene holds for frames of this kind                 */
 } rtmi_counters;
 
 typedef struct rtmi_scene rtmi_scene;

@@ -69,7 +69,8 @@ class Counters(C.Structure):
                 ("shadow_rays_elided", C.c_int64), ("node_tests", C.c_int64), ("tri_candidates", C.c_int64), ("ms_total", C.c_double), ("ms_tri_search", C.c_double),
                 ("tri_search_launches", C.c_int64), ("tri_tests_primary_kernel", C.c_int64),
                 ("ms_primary_kernel", C.c_double), ("ms_shade", C.c_double), ("primary_rays_traced", C.c_int64),
-                ("hits_decided_fp32", C.c_int64), ("pixels_fixed_fp64", C.c_int64)]
+                ("hits_decided_fp32", C.c_int64), ("pixels_fixed_fp64", C.c_int64),
+                ("tri_edge_tests", C.c_int64), ("work_buffer_bytes", C.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved_"}

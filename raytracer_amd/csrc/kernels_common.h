@@ -73,6 +73,7 @@ struct FrameConst {
 // per-wave atomic adds of a launch do not serialise on one address; the host sums the slots.
 enum { C_REFL = 0, C_SHADOW, C_EXACT, C_HITS, C_TESTS_PRIMARY, C_TESTS_SECONDARY, C_SHADOW_ELIDED, C_NODE_TESTS, C_PRIMARY_TRACED,
        C_FIX_PIXELS,   // pixels whose bytes the FP32 lighting could not settle: evaluated again in FP64 (k_fix_pixels)
+       C_EDGE_TESTS,   // cone tree: (ray, triangle) pairs that went through the FP32 edge test
        C_FP32_DECIDED, // single candidates accepted by the FP32 tests alone (inside the triangle and the bounding sphere by a margin)
        C_NCOUNTERS = 16 };
 constexpr int NSLOT = 64;

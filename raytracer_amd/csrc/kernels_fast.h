@@ -183,7 +183,9 @@ k_shade_candidates_fast(FrameConst fc, SceneDev sc, FastArgs fa, const SearchArg
             rtx32::MatF m;
             if (mi < FAST_LDS_MATS) m = s_mats[mi];
             else m = fa.mats[min(mi, fa.n_materials - 1)];
-            col = rtx32::shade_hit(dx, dy, dz, fa.dir_err, pl.x, pl.y, pl.z, pl.w, m, s_lights, sc.n_lights, fa.ns_uniform);
+            // (ns_uniform is a kernel argument: the branch and the powering loop behind it are scalar code)
+            if (fa.ns_uniform) col = rtx32::shade_hit<true>(dx, dy, dz, fa.dir_err, pl.x, pl.y, pl.z, pl.w, m, s_lights, sc.n_lights, fa.ns_uniform);
+            else col = rtx32::shade_hit<false>(dx, dy, dz, fa.dir_err, pl.x, pl.y, pl.z, pl.w, m, s_lights, sc.n_lights);
           }
           rgbf[s] = make_float4(col.r, col.g, col.b, col.err);
         }

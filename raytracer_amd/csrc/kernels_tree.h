@@ -241,7 +241,7 @@ __device__ __forceinline__ void search_tree_body(const SearchArgs* __restrict__ 
         if (nearest) tval[sid[r]] = __builtin_inf();
       }
   }
-  unsigned n_leaf_rec = 0, n_node_rec = 0;
+  unsigned n_leaf_rec = 0, n_node_rec = 0, n_edge_tri = 0;
   int fill = 0;
   // per ray of the lane: -1 no candidate so far, -2 several, else the list position of its only one (SearchArgs::singles)
   int pos1[R];
@@ -288,6 +288,7 @@ __device__ __forceinline__ void search_tree_body(const SearchArgs* __restrict__ 
 #pragma unroll
         for (int r = 1; r < R; ++r) mq = __builtin_fmaxf(mq, h ? q[r].y : q[r].x);
         if (!__any(mq >= 1.0f) && !((always >> jj) & 1u)) continue;
+        ++n_edge_tri;
         const float* m = edge + jj * EDGE_FLOATS;
         const float m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3], m4 = m[4], m5 = m[5], m6 = m[6], m7 = m[7], m8 = m[8];
         const int pos = checked(slot_pos[ri * 8 + jj], ap->n_group, ap->cnt, 4);  // the triangle's position in the group's list order
@@ -391,14 +392,18 @@ __device__ __forceinline__ void search_tree_body(const SearchArgs* __restrict__ 
   DevCounters* cnt = ap->cnt;
   wave_count(cnt, C_TESTS_PRIMARY, lane == 0 ? 8ull * n_leaf_rec * (unsigned long long)active : 0ull);
   wave_count(cnt, C_NODE_TESTS, lane == 0 ? 8ull * n_node_rec * (unsigned long long)active : 0ull);
+  wave_count(cnt, C_EDGE_TESTS, lane == 0 ? (unsigned long long)n_edge_tri * (unsigned long long)active : 0ull);
   if constexpr (FAST) wave_count(cnt, C_PRIMARY_TRACED, lane == 0 ? (unsigned long long)active : 0ull);
 }
 
 #ifndef RTMI_TREE_WAVES
 #define RTMI_TREE_WAVES 7
 #endif
+#ifndef RTMI_TREE_WAVES_GENERAL
+#define RTMI_TREE_WAVES_GENERAL 6
+#endif
 template <int R>
-__global__ void __launch_bounds__(256, R <= 4 ? RTMI_TREE_WAVES : 6)
+__global__ void __launch_bounds__(256, R <= 4 ? RTMI_TREE_WAVES_GENERAL : 6)
 k_search_tree(const SearchArgs* __restrict__ ap, const f2* __restrict__ rec, const float* __restrict__ edge_all,
               const int* __restrict__ slot_pos, int parity) {
   search_tree_body<R, false>(ap, rec, edge_all, slot_pos, parity, nullptr, nullptr, (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));

@@ -312,12 +312,13 @@ struct rtmi_scene {
   // one frame may be in flight between rtmi_render_begin and rtmi_render_end
   bool pending = false;
   DevCounters* h_cnt = nullptr;  // pinned host copy of the device counters
-  std::vector<std::array<hipEvent_t, 3>> ev_pool;  // per search launch: before, after the search, after its shading; reused
+  std::vector<std::array<hipEvent_t, 4>> ev_pool;  // per search launch: before, after the search, after its shading, after the walk or scan kernel alone; reused
   size_t ev_used = 0;
   long long pend_launches = 0;
   int64_t pend_live_samples = 0;
   bool pend_shade_timed = false;
   bool pend_fast = false;  // the frame in flight runs without a ray-generation launch
+  int64_t pend_work_bytes = 0;  // device memory of the work buffers the frame uses
   rtmi_camera pend_cam{};
   rtmi_params pend_params{};
   void* pend_rgba = nullptr;
@@ -672,7 +673,7 @@ static int32_t scene_create_impl(const rtmi_scene_desc* desc, int32_t device, rt
   HIP_TRY(hipMalloc(&sc->wb.cnt, sizeof(DevCounters)));
   // one triple of timing events per triangle group: what a frame of one batch needs
   for (size_t g = 0; g < sc->groups.size(); ++g) {
-    std::array<hipEvent_t, 3> t{};
+    std::array<hipEvent_t, 4> t{};
     for (hipEvent_t& e : t) HIP_TRY(hipEventCreate(&e));
     sc->ev_pool.push_back(t);
   }
@@ -1440,7 +1441,7 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
         g_last_error = "rtmi_render_device_noalloc: out of timing events";
         return RTMI_ERR_UNSUPPORTED;
       }
-      std::array<hipEvent_t, 3> t{};
+      std::array<hipEvent_t, 4> t{};
       for (hipEvent_t& e : t) HIP_TRY(hipEventCreate(&e));
       sc->ev_pool.push_back(t);
     }
@@ -1485,6 +1486,7 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
         fa.pos_mt = g.d_pos_mt;
         hipLaunchKernelGGL(tree_fast, dim3(fgrid), dim3(256), 0, st, sc->d_sargs + gi, (const f2*)g.d_rec, (const float*)g.d_tedge,
                            (const int*)g.d_slot_pos, par, fcb, fa);
+        HIP_TRY(hipEventRecord(ev[3], st));
         hipLaunchKernelGGL(k_search_exact_multi_fast, dim3(sc->exact_grid), dim3(256), 0, st, sc->d_sargs + gi, par, fcb, fa);
         HIP_TRY(hipEventRecord(ev[1], st));
         hipLaunchKernelGGL(k_shade_candidates_fast, dim3(sc->fast_shade_grid), dim3(256), 0, st, fcb, sc->dev, fa, sc->d_sargs + gi, par);
@@ -1516,6 +1518,7 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
         launch_parity ^= 1;
         hipLaunchKernelGGL(tree_kernel, dim3(search_grid), dim3(256), 0, st, sc->d_sargs + gi, (const f2*)g.d_rec,
                            (const float*)g.d_tedge, (const int*)g.d_slot_pos, par);
+        HIP_TRY(hipEventRecord(ev[3], st));
         if (nearest) {
           hipLaunchKernelGGL(k_search_exact<true>, dim3(sc->exact_grid), dim3(256), 0, st, sc->d_sargs + gi, par);
           hipLaunchKernelGGL(k_search_nearest, dim3(sc->exact_grid), dim3(256), 0, st, sc->d_sargs + gi, par);
@@ -1548,6 +1551,7 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
         }
       } else {
         hipLaunchKernelGGL(scan_kernel, dim3(search_grid), dim3(256), 0, st, sc->d_sargs + gi, (const f2*)g.d_cone);
+        HIP_TRY(hipEventRecord(ev[3], st));
         HIP_TRY(hipEventRecord(ev[1], st));
       }
       HIP_TRY(hipEventRecord(ev[2], st));
@@ -1635,6 +1639,17 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
   sc->pend_live_samples = live_samples;
   sc->pend_shade_timed = shade_queue_launched;
   sc->pend_fast = fast;
+  {
+    const size_t blk = sc->wb.cap_blocks * (sizeof(int2) + 1) + sc->wb.cap_tabs * (sizeof(double) + sizeof(float)) + sizeof(DevCounters);
+    if (fast) {
+      const FastBufs& f = sc->fast;
+      sc->pend_work_bytes = (int64_t)(f.cap_samples * (2 * sizeof(int) + sizeof(float4)) + (f.cap_cand + f.cap_multi) * sizeof(int2) +
+                                      f.cap_fix * sizeof(int) + f.cap_live * sizeof(int2) + f.cap_slots * sizeof(int) + f.cap_consts + blk);
+    } else {
+      const WorkBufs& w = sc->wb;
+      sc->pend_work_bytes = (int64_t)(w.cap_samples * (6 * sizeof(int) + 7 * sizeof(double)) + (w.cap_cand + w.cap_multi) * sizeof(int2) + blk);
+    }
+  }
   sc->pend_cam = *cam;
   sc->pend_params = *p;
   sc->pend_rgba = rgba_dev;
@@ -1720,12 +1735,14 @@ static int32_t render_finish(rtmi_scene* sc, rtmi_counters* counters) {
     g_last_error = "internal index check " + std::to_string(hc.bug) + " failed on the device; the frame is not valid";
     return RTMI_ERR_HIP;
   }
-  float ms_total = 0.f, ms_search = 0.f, ms_shade = 0.f;
+  float ms_total = 0.f, ms_search = 0.f, ms_shade = 0.f, ms_walk = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms_total, sc->ev_a, sc->ev_b));
   for (size_t i = 0; i < sc->ev_used; ++i) {
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, sc->ev_pool[i][0], sc->ev_pool[i][1]));
     ms_search += ms;
+    HIP_TRY(hipEventElapsedTime(&ms, sc->ev_pool[i][0], sc->ev_pool[i][3]));
+    ms_walk += ms;
     HIP_TRY(hipEventElapsedTime(&ms, sc->ev_pool[i][1], sc->ev_pool[i][2]));
     ms_shade += ms;
   }
@@ -1759,7 +1776,9 @@ static int32_t render_finish(rtmi_scene* sc, rtmi_counters* counters) {
     counters->ms_tri_search = ms_search;
     counters->tri_search_launches = sc->pend_launches;
     counters->tri_tests_primary_kernel = (int64_t)sum[C_TESTS_PRIMARY];
-    counters->ms_primary_kernel = ms_search;
+    counters->ms_primary_kernel = ms_walk;
+    counters->tri_edge_tests = (int64_t)sum[C_EDGE_TESTS];
+    counters->work_buffer_bytes = sc->pend_work_bytes;
     counters->ms_shade = ms_shade;
   }
   return RTMI_OK;

@@ -88,24 +88,31 @@ RT_HD void powi2(float lo, float hi, int n, float* plo, float* phi) {
   *phi = rh;
 }
 
+// (a NaN may come out as 0 or 1 here: every NaN among the colour terms is one among the error terms too, and flags the sample)
+#if defined(__HIP_DEVICE_COMPILE__)
+RT_HD float clamp01f(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 1.0f); }
+#else
 RT_HD float clamp01f(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
+#endif
 RT_HD float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 
 // d: unit primary direction (error dir_err); n, num: the triangle's plane as described above.
-// ns_loop: the exponent when the caller knows it without looking at the material (the same for every lane of a wave: the
-// powering loop is then scalar code), else 0.
+// UNIFORM_NS: the caller passes the exponent in ns_uniform and vouches that every material has that one (on the GPU the
+// value then sits in a scalar register and the powering loop is scalar code: four packed multiplications for Ns = 8
+// instead of four trips through a loop under an execution mask); else the material's own exponent is used.
+template <bool UNIFORM_NS = false>
 #if defined(__HIPCC__)
 #define RT_HD_FLAT __host__ __device__ __forceinline__
 #else
 #define RT_HD_FLAT inline __attribute__((always_inline))
 #endif
 RT_HD_FLAT Shade32 shade_hit(float dx, float dy, float dz, float dir_err, float nx, float ny, float nz, float num, const MatF& m,
-                             const LightF* lights, int n_lights, int ns_loop = 0) {
+                             const LightF* lights, int n_lights, int ns_uniform = 0) {
   // (fused multiply-adds are written out: the translation unit is built without contraction, and a fused operation
   // only ever has less rounding error than the two the model above charges)
   const float inf = __builtin_inff();
   Shade32 out;
-  bool flag = m.ns < 1;
+  bool flag = (UNIFORM_NS ? ns_uniform : m.ns) < 1;
   const float nd = -__builtin_fmaf(nz, dz, __builtin_fmaf(ny, dy, nx * dx));
   const float dn = dir_err + 6.0f * U;
   if (!(nd > 8.0f * dn)) flag = true;
@@ -144,7 +151,7 @@ RT_HD_FLAT Shade32 shade_hit(float dx, float dy, float dz, float dir_err, float 
       // rv* lies in [rv - drv, rv + drv] and x -> max(x, 0)^Ns is monotonic: its value lies between the powers of the
       // two ends (each computed to 14u relative); the midpoint stands for it, half the width is its error
       float plo, phi;
-      powi2(fmaxf(rv - drv, 0.0f), rv + drv, ns_loop ? ns_loop : m.ns, &plo, &phi);
+      powi2(fmaxf(rv - drv, 0.0f), rv + drv, UNIFORM_NS ? ns_uniform : m.ns, &plo, &phi);
       const float spec = 0.5f * (plo + phi);
       const float espec = __builtin_fmaf(0.5f, phi - plo, 16.0f * U * phi);
       r += clamp01f(m.sr * L.sr * spec); g += clamp01f(m.sg * L.sg * spec); b += clamp01f(m.sb * L.sb * spec);  // RTF:259-266

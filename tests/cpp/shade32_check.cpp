@@ -122,7 +122,8 @@ int main(int argc, char** argv) {
       MF.sr = (float)m.Ks[0]; MF.sg = (float)m.Ks[1]; MF.sb = (float)m.Ks[2];
       MF.smax = rtx32::max3f(fabsf(MF.sr), fabsf(MF.sg), fabsf(MF.sb));
       MF.ns = (int)m.Ns;
-      const rtx32::Shade32 o = rtx32::shade_hit(dx, dy, dz, dir_err, (float)nrm.x, (float)nrm.y, (float)nrm.z, (float)num, MF, LF, nl);
+      const rtx32::Shade32 o = (next(s) & 1) ? rtx32::shade_hit<true>(dx, dy, dz, dir_err, (float)nrm.x, (float)nrm.y, (float)nrm.z, (float)num, MF, LF, nl, MF.ns)
+                                             : rtx32::shade_hit<false>(dx, dy, dz, dir_err, (float)nrm.x, (float)nrm.y, (float)nrm.z, (float)num, MF, LF, nl);
       if (!(o.err < 1.0f)) { ++flagged; continue; }
       const float got[3] = {o.r, o.g, o.b};
       for (int c = 0; c < 3; ++c) {
