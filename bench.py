@@ -79,9 +79,11 @@ def pmc_kernel(config, kernel):
     return d.get(config, {}).get(kernel)
 
 
-def pmc_fractions(k):
+def pmc_fractions(k, live_ms=None):
     """What the hardware executed, from the counters of one launch (formulas spelled out in the result):
-    executed FP64 (or FP32) flops per second against the peak, and the share of cycles the VALU issued."""
+    executed FP64 (or FP32) flops per second against the peak, and the share of cycles the VALU issued.
+    live_ms: this run's average duration of the same kernel; the result then says how far the profiled launch is from
+    it (`launch_ms_drift_frac`) and calls itself stale above 10 %."""
     if not k:
         return None
     ms = k["avg_launch_ms"]
@@ -107,6 +109,9 @@ def pmc_fractions(k):
         out["valu_issue_formula"] = "SQ_ACTIVE_INST_VALU x 4 cycles / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)"
     if k.get("hbm_bytes_per_launch"):
         out["hbm_bytes_per_launch"] = k["hbm_bytes_per_launch"]
+    if live_ms and live_ms > 0:
+        out["launch_ms_drift_frac"] = round(abs(live_ms - ms) / ms, 4)
+        out["stale"] = out["launch_ms_drift_frac"] > 0.10
     return out
 
 
@@ -665,7 +670,7 @@ def walk_roofline(args, totals, steps):
     flops = 6.0 * (node + tri) + 18.0 * edge + 18.0 * traced
     achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     kernel = "k_search_tree_fast<4>"
-    pmc = pmc_fractions(pmc_kernel(args.config, kernel))
+    pmc = pmc_fractions(pmc_kernel(args.config, kernel), ms)
     return {
         "bound": "valu_fp32",
         "kernel": kernel,
@@ -711,7 +716,7 @@ def shade_roofline(args, totals, steps, n_lights, inert):
     # candidate entry 8 + best position 4 + direction 24 (+ the triangle 72 and its plane 32 where the pair is decided
     # here) read; hit id 4 + colour 24 written
     bytes_hit = 64 + (104 if args.form == "B" else 0)
-    pmc = pmc_fractions(pmc_kernel(args.config, kernel))
+    pmc = pmc_fractions(pmc_kernel(args.config, kernel), ms_shade)
     return {
         "bound": "valu_fp64",
         "kernel": kernel,
@@ -721,7 +726,7 @@ def shade_roofline(args, totals, steps, n_lights, inert):
         "frac": round(achieved / PEAK_FP64_TFLOPS, 4),
         "traffic": pmc.get("hbm_bytes_per_launch") if pmc else None,
         "traffic_unit": "bytes of HBM traffic per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes; "
-                        "profiles/r02_pmc_kernels.json)",
+                        + os.path.relpath(PMC_FILE, ROOT) + ")",
         "flops_per_hit_algorithmic": flops_hit,
         "flops_per_hit_as_the_reference_evaluates_it": flops_hit_ref,
         "hits_per_launch": hits,
@@ -749,7 +754,7 @@ def shade_roofline(args, totals, steps, n_lights, inert):
 
 def scan_roofline(tests_per_launch, avg_ms, config):
     """The list-scan kernel: evaluated pairs and what the hardware executed for them."""
-    pmc = pmc_fractions(pmc_kernel(config, "k_search_primary<4>"))
+    pmc = pmc_fractions(pmc_kernel(config, "k_search_primary<4>"), avg_ms)
     r = {
         "bound": "valu_fp32",
         "kernel": "k_search_primary<4>",
