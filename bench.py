@@ -465,7 +465,7 @@ def run_tiled_frames(args, rtm):
                          for r, v in enumerate(per_rank)],
             "roofline": roofline,
         }
-        for k in ("static_camera", "list_scan", "form_T", "shadows_enter_bounded"):
+        for k in ("static_camera", "two_frames_in_flight", "list_scan", "form_T", "shadows_enter_bounded"):
             if k in aux:
                 out[k] = aux[k]
         if not args.no_cpu and world == 1:
@@ -804,6 +804,26 @@ def aux_legs(rt, scene, data, params, frame, camera_for, args, level, n_lights):
     # the camera held still: camera-dependent preparation (sample tables, cone tree) is reused
     ms, _ = run(scene, params, [scenes.make_camera(**scenes.MESH_CAMERA)] * 5)
     out["static_camera"] = {"ms_per_step": round(ms, 4), "steps": 5}
+    # the timed frames again with two of them in flight (two scene objects, each with a stream and work buffers of its
+    # own: what a rank of a multi-GPU run does): the launches of one frame fill the gaps of the other
+    other = rt.Scene(data, device=scene.device)
+    frames2 = [frame, torch.empty_like(frame)]
+    pair, flying, n2 = [scene, other], [], args.steps
+    torch.cuda.synchronize()
+    for leg in range(2):  # the first pass warms the second scene up
+        traced = 0
+        t0 = time.perf_counter()
+        for i in range(n2):
+            if len(flying) == 2:
+                traced += flying.pop(0).render_end()["primary_rays_traced"]
+            pair[i & 1].render_begin(camera_for(args.warmup + i), params, frames2[i & 1].data_ptr())
+            flying.append(pair[i & 1])
+        while flying:
+            traced += flying.pop(0).render_end()["primary_rays_traced"]
+        ms = (time.perf_counter() - t0) / n2 * 1e3
+    other.close()
+    out["two_frames_in_flight"] = {"ms_per_step": round(ms, 4), "steps": n2, "mrays_per_s": round(traced / n2 / (ms * 1e-3) / 1e6, 1),
+                                   "note": "same frames as the timed region, frame i+1 enqueued before frame i is waited for"}
     if args.search == "tree" and not args.no_scan_leg:
         p = copy.copy(params)
         p.search = _abi.RTMI_SEARCH_LIST_SCAN
