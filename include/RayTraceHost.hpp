@@ -205,7 +205,9 @@ inline void raytraceWorld(v3d camera, v3d cameraDirection, double focalLength, i
   p.pixel_subdivision = pixelSubdivision;
   p.ambient[0] = ambientLight.red; p.ambient[1] = ambientLight.green; p.ambient[2] = ambientLight.blue;
   p.hit_policy = extensions.nearestHit ? RTMI_HIT_NEAREST : RTMI_HIT_LIST_ORDER;
-  p.flags = (extensions.shadowMaxDistance ? RTMI_FLAG_SHADOW_MAX_DISTANCE : 0) |
+  // (the reference keeps no ray counts, so none are asked for: same pixels, and the library may skip rays that cannot
+  // change one)
+  p.flags = RTMI_FLAG_NO_RAY_STATISTICS | (extensions.shadowMaxDistance ? RTMI_FLAG_SHADOW_MAX_DISTANCE : 0) |
             (extensions.shadowsEnterBounded ? RTMI_FLAG_SHADOWS_ENTER_BOUNDED : 0) |
             (extensions.reflectionsEnterBounded ? RTMI_FLAG_REFLECTIONS_ENTER_BOUNDED : 0);
   rtmi_counters counters{};

@@ -118,7 +118,8 @@ public func raytraceWorld(camera: V3, cameraDirection: V3, focalLength: Double, 
     p.pixel_subdivision = pixelSubdivision  // :170 hard-codes 1; 0.5 = 4 samples per pixel, 0.25 = 16
     p.ambient = tuple(ambientLight)
     p.hit_policy = Int32((extensions.nearestHit ? RTMI_HIT_NEAREST : RTMI_HIT_LIST_ORDER).rawValue)
-    p.flags = (extensions.shadowMaxDistance ? RTMI_FLAG_SHADOW_MAX_DISTANCE : 0) |
+    // (the reference keeps no ray counts, so none are asked for: same pixels, and the library may skip rays that cannot change one)
+    p.flags = RTMI_FLAG_NO_RAY_STATISTICS | (extensions.shadowMaxDistance ? RTMI_FLAG_SHADOW_MAX_DISTANCE : 0) |
               (extensions.shadowsEnterBounded ? RTMI_FLAG_SHADOWS_ENTER_BOUNDED : 0) |
               (extensions.reflectionsEnterBounded ? RTMI_FLAG_REFLECTIONS_ENTER_BOUNDED : 0)
     p.search = Int32(RTMI_SEARCH_CONE_TREE.rawValue)
