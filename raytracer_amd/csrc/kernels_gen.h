@@ -22,7 +22,10 @@ constexpr int GEN_ITERS = RTMI_GEN_ITERS;  // samples per thread in k_gen; a wor
 // for the object if cos(theta - phi) stays below the cosine the per-sample pre-test of k_gen demands (whose
 // margin covers the rounding here, FP64, many times over).  A cleared block is never touched by k_gen and
 // written as black by k_resolve.
-__device__ inline bool block_is_live(const FrameConst& fc, int2 bc) {
+// The vector from the camera to the centre of block bc on the focal plane, its length, and rho.  False for a patch that
+// is wide as seen from the camera (or a NaN): no bound on phi then.
+__device__ inline bool block_centre(const FrameConst& fc, int2 bc, double* dx_out, double* dy_out, double* dz_out, double* len_out,
+                                    double* rho_out) {
   const double ic = bc.x * BLK + 0.5 * BLK, jc = bc.y * BLK + 0.5 * BLK;
   const double hu = ic / fc.ppw_h, hv = jc / fc.ppw_v;
   const double dx = (fc.ul[0] - fc.cam[0]) + fc.u[0] * hu - fc.v[0] * hv;
@@ -30,7 +33,13 @@ __device__ inline bool block_is_live(const FrameConst& fc, int2 bc) {
   const double dz = (fc.ul[2] - fc.cam[2]) + fc.u[2] * hu - fc.v[2] * hv;
   const double len = sqrt(dx * dx + dy * dy + dz * dz);
   const double rho = 1.001 * (0.5 * BLK / fabs(fc.ppw_h) + 0.5 * BLK / fabs(fc.ppw_v));
-  bool live = !(len > 4.0 * rho);  // a patch that is wide as seen from the camera (or a NaN) is not cleared
+  *dx_out = dx; *dy_out = dy; *dz_out = dz; *len_out = len; *rho_out = rho;
+  return len > 4.0 * rho;
+}
+
+__device__ inline bool block_is_live(const FrameConst& fc, int2 bc) {
+  double dx, dy, dz, len, rho;
+  bool live = !block_centre(fc, bc, &dx, &dy, &dz, &len, &rho);  // a patch without a bound is not cleared
   if (!live) {
     const double sphi = rho / len, cphi = sqrt(1.0 - sphi * sphi);
     for (int o = 0; o < fc.n_genf && !live; ++o) {

@@ -115,7 +115,18 @@ struct FastArgs {
   int* fix_list;              // pixels for k_fix_pixels: NSLOT lists of fix_cap / NSLOT entries
   int fix_cap;
   int force;                  // tests: bit 0 = no pair is accepted by the FP32 margins, bit 1 = every pixel goes to k_fix_pixels
+  const int* entries;         // per live block ENTRY_K records where the walks of its waves start (k_block_entries); null: at the root
 };
+
+// Where the walk of a block's waves starts.  Every direction of an 8x8 pixel block lies within a small angle of the
+// direction to the block's centre, so the upper records of the tree give the same answer for all waves of the block --
+// and mostly "one or two children" -- which one work-item per block finds out beforehand (k_block_entries) instead of
+// every lane of every wave: the records a wave would enter from the root are replaced by their children that the block
+// can reach, as long as at most ENTRY_K records result.  An entry is (level << ENTRY_SHIFT) | record index, -1 = none.
+constexpr int ENTRY_K = 8;
+constexpr int ENTRY_SHIFT = 27;
+constexpr int ENTRY_FINAL = 1 << 30;  // (inside k_block_entries only) this entry is not expanded any further
+static_assert(ENTRY_K == 8, "k_block_entries keeps a block's list in the eight lanes of a group");
 
 // Every kernel of the path starts with this: the number of live blocks is only known on the device.
 __device__ __forceinline__ void fast_live_counts(FastArgs& fa, const FrameConst& fc, const DevCounters* cnt) {
@@ -341,37 +352,70 @@ __device__ __forceinline__ void search_tree_body(const SearchArgs* __restrict__ 
     }
   };
 
-  if (ltop == 0) {
-    for (int t = 0; t < n_root; ++t) leaf(t);
-  } else {
-    for (int t = 0; t < n_root; ++t) {
-      int lvl = ltop, ri = t;
-      unsigned long long masks;
-      {
-        unsigned m = tree_eval<R>(rec + (size_t)checked(level_off(lvl) + ri, n_records, ap->cnt, 5) * (REC_DWORDS / 2), dx, dy, dz);
-        masks = (unsigned long long)m << (8 * lvl);
-        ++n_node_rec;
+  // where the walk starts: at the root record(s), or at the records k_block_entries found for the block of this wave's
+  // samples (FAST, and the wave's R groups of 64 samples belong to one block)
+  const int* entries = nullptr;
+  if constexpr (FAST) {
+    if (fap->entries) {
+      // (the wave's number is the same in all its lanes, which the compiler cannot know: without the readfirstlane the
+      // whole walk below would count as divergent control flow and keep its state in vector registers)
+      const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+      int b0, b1, kx, ky;
+      const int t_last = min(wave_u * R + R - 1, (nq >> 6) - 1);
+      group_coords(*fcp, wave_u * R, &b0, &kx, &ky);
+      group_coords(*fcp, t_last, &b1, &kx, &ky);
+      b0 = __builtin_amdgcn_readfirstlane(b0);
+      b1 = __builtin_amdgcn_readfirstlane(b1);
+      if (b0 == b1 && (unsigned)b0 < (unsigned)fap->cap_live) entries = fap->entries + (size_t)b0 * ENTRY_K;
+    }
+  }
+  const int n_start = entries ? ENTRY_K : n_root;
+#pragma nounroll
+  for (int t = 0; t < n_start; ++t) {
+    // a start is a record (top, ri) with top >= 1, or a leaf record: the latter enters the loop below as the only
+    // pending child of its (unevaluated) parent, so that the leaf code exists once
+    int top = ltop, ri = t;
+    if (entries) {
+      const int e = __builtin_amdgcn_readfirstlane(entries[t]);
+      if (e < 0) break;
+      top = (e >> ENTRY_SHIFT) & 7;
+      ri = e & ((1 << ENTRY_SHIFT) - 1);
+      if (top > ltop) {  // only a defective entry can lead here
+        ap->cnt->bug = 6;
+        break;
       }
-      for (;;) {
-        const unsigned cur = (unsigned)(masks >> (8 * lvl)) & 0xffu;
-        if (cur == 0) {
-          if (lvl == ltop) break;
-          ++lvl;
-          ri >>= 3;
-          continue;
-        }
-        const int c = __builtin_ctz(cur);
-        masks &= ~(1ull << (8 * lvl + c));
-        const int child = ri * 8 + c;
-        if (lvl == 1) {
-          leaf(child);
-        } else {
-          --lvl;
-          ri = child;
-          unsigned m = tree_eval<R>(rec + (size_t)checked(level_off(lvl) + ri, n_records, ap->cnt, 5) * (REC_DWORDS / 2), dx, dy, dz);
-          masks |= (unsigned long long)m << (8 * lvl);
-          ++n_node_rec;
-        }
+    }
+    int lvl;
+    unsigned long long masks;
+    if (top == 0) {
+      masks = 1ull << (8 + (ri & 7));
+      ri >>= 3;
+      top = lvl = 1;
+    } else {
+      lvl = top;
+      unsigned m = tree_eval<R>(rec + (size_t)checked(level_off(lvl) + ri, n_records, ap->cnt, 5) * (REC_DWORDS / 2), dx, dy, dz);
+      masks = (unsigned long long)m << (8 * lvl);
+      ++n_node_rec;
+    }
+    for (;;) {
+      const unsigned cur = (unsigned)(masks >> (8 * lvl)) & 0xffu;
+      if (cur == 0) {
+        if (lvl == top) break;
+        ++lvl;
+        ri >>= 3;
+        continue;
+      }
+      const int c = __builtin_ctz(cur);
+      masks &= ~(1ull << (8 * lvl + c));
+      const int child = ri * 8 + c;
+      if (lvl == 1) {
+        leaf(child);
+      } else {
+        --lvl;
+        ri = child;
+        unsigned m = tree_eval<R>(rec + (size_t)checked(level_off(lvl) + ri, n_records, ap->cnt, 5) * (REC_DWORDS / 2), dx, dy, dz);
+        masks |= (unsigned long long)m << (8 * lvl);
+        ++n_node_rec;
       }
     }
   }
@@ -418,6 +462,97 @@ k_search_tree_fast(const SearchArgs* __restrict__ ap, const f2* __restrict__ rec
   // 5 to 20 % slower: the hardware's own dispatch balances waves of unequal work better than a fixed stride does.)
   fast_live_counts(fa, fc, ap->cnt);
   search_tree_body<R, true>(ap, rec, edge_all, slot_pos, parity, &fc, &fa, (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+}
+
+// One work-item per live block: the records at which the walks of the block's waves start (see ENTRY_K).
+// A child of a record can be reached by a ray of the block only if the direction c to the block's centre makes an angle
+// of at most theta + Phi with the child's axis a, where theta is the half-angle the child's stored vector stands for
+// (w = a / cos(theta): the walk passes a ray iff d.w >= 1) and Phi bounds the angle between c and any direction the walk
+// may test for the block: phi of block_is_live, plus the distance between the FP32 directions and the reference's.
+// With |w| = 1 / cos(theta):  cos(angle(c, a)) >= cos(theta + Phi)  <=>  c.w - cos(Phi) >= -sin(Phi) sqrt(|w|^2 - 1),
+// which is decided without a root or a division: q = c.w - cos(Phi) is non-negative, or q^2 <= sin^2(Phi) (|w|^2 - 1).
+// Everything here is FP64 on the walk's own FP32 operands, with slack of 1e-6 relative and 1e-9 absolute; the test
+// is only ever more permissive than the walk's.  A block without a bound on phi starts at the root.
+// Eight lanes per block: lane j of the group holds entry j of the block's list and tests child j of the record that is
+// being expanded.  All groups of a wave step together (the cross-lane operations are wave-wide); a group that is done
+// idles until the wave's last one is.
+__global__ void __launch_bounds__(256)
+k_block_entries(FrameConst fc, FastArgs fa, const f2* __restrict__ rec_all, TreeDev T, int n_records, DevCounters* cnt, int* entries_out) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int slot = tid >> 3, j = tid & 7;
+  const int lane = threadIdx.x & 63, g0 = lane & ~7;  // first lane of the group
+  const int n_live = min(max(cnt->n_live, 0), fa.cap_live);
+  const bool exists = slot < n_live;
+  int e = -1;  // this lane's entry
+  double cx = 0.0, cy = 0.0, cz = 0.0, sPhi = 1.0, cPhi = 0.0;
+  if (exists) {
+    double dx, dy, dz, len, rho;
+    const bool bounded = block_centre(fc, fa.blocks[slot], &dx, &dy, &dz, &len, &rho);
+    sPhi = rho / len + 2.0 * (double)fa.dir_err + 2.0e-6;
+    const bool usable = T.n_root == 1 && bounded && sPhi < 0.5 && T.ltop >= 1;
+    cPhi = sqrt(fmax(0.0, 1.0 - sPhi * sPhi));
+    cx = dx / len; cy = dy / len; cz = dz / len;
+    if (j == 0) e = (T.ltop << ENTRY_SHIFT) | (usable ? 0 : ENTRY_FINAL);
+  }
+  const float* rec = reinterpret_cast<const float*>(rec_all);
+  for (int iter = 0; iter < 8 * ENTRY_K; ++iter) {
+    // the group's entry of the highest level that may still be expanded: the largest key wins
+    const int lvl_e = (e >> ENTRY_SHIFT) & 7;
+    const bool open = e >= 0 && !(e & ENTRY_FINAL) && lvl_e >= 1;
+    int key = open ? ((lvl_e << 3) | j) : -1;
+    for (int sh = 1; sh < 8; sh <<= 1) key = max(key, __shfl_xor(key, sh));
+    if (!__any(key >= 0)) break;  // every group of the wave is done
+    const bool active = key >= 0;
+    const int pick = active ? (key & 7) : 0;
+    const int pe = __shfl(e, g0 + pick);
+    const int pick_lvl = (pe >> ENTRY_SHIFT) & 7;
+    const int ri = pe & ((1 << ENTRY_SHIFT) - 1);
+    bool pass = false;
+    if (active) {
+      const int rix = checked(T.rec_off[pick_lvl] + ri, n_records, cnt, 7);
+      const float* rp = rec + (size_t)rix * REC_DWORDS;
+      const unsigned always = reinterpret_cast<const unsigned*>(rp)[REC_ALWAYS];
+      const float* w = rp + (j >> 1) * 6 + (j & 1);
+      const double wx = w[0], wy = w[2], wz = w[4];
+      const double wl2 = wx * wx + wy * wy + wz * wz;
+      if (wl2 != wl2 || ((always >> j) & 1u)) {
+        pass = true;  // a wide child: always entered
+      } else if (wl2 > 0.0) {  // (an absent or culled child has the zero vector: never entered)
+        const double slack = 1.0e-9 * (1.0 + wl2);
+        const double q = (cx * wx + cy * wy + cz * wz) - cPhi;
+        pass = q >= -slack || q * q <= sPhi * sPhi * fmax(wl2 - 1.0, 0.0) * 1.000001 + slack;
+      }
+    }
+    const unsigned long long pb = __ballot(pass), eb = __ballot(e >= 0);
+    const unsigned mask = (unsigned)(pb >> g0) & 0xffu;  // children to enter
+    const unsigned have = (unsigned)(eb >> g0) & 0xffu;  // entries held
+    const int k = __popc(mask), n = __popc(have);
+    const bool expand = active && n - 1 + k <= ENTRY_K;
+    // the new list: the entries kept (all but the picked one), then the children
+    const unsigned kept = expand ? (have & ~(1u << pick)) : have;
+    const int n_kept = __popc(kept);
+    // source lane of the entry that moves to place j: the j-th set bit of `kept`
+    int src = 0, seen = 0, child_bit = 0, seen_c = 0;
+    for (int q = 0; q < 8; ++q) {
+      if ((kept >> q) & 1u) { if (seen == j) src = q; ++seen; }
+      if ((mask >> q) & 1u) { if (seen_c == j - n_kept) child_bit = q; ++seen_c; }
+    }
+    const int moved = __shfl(e, g0 + src);
+    if (active && !expand) {
+      if (j == pick) e |= ENTRY_FINAL;
+    } else if (expand) {
+      if (j < n_kept) {
+        e = moved;
+      } else if (j < n_kept + k) {
+        const long long child = (long long)ri * 8 + child_bit;
+        if (child >= (1ll << ENTRY_SHIFT)) { cnt->bug = 8; e = -1; }  // cannot happen: the host leaves such trees to the root
+        else e = ((pick_lvl - 1) << ENTRY_SHIFT) | (int)child;
+      } else {
+        e = -1;
+      }
+    }
+  }
+  if (exists) entries_out[(size_t)slot * ENTRY_K + j] = e >= 0 ? (e & ~ENTRY_FINAL) : -1;
 }
 
 // One lane per candidate: the reference's own arithmetic in FP64; a hit competes for the ray's

@@ -144,6 +144,7 @@ struct FastBufs {
   int* fix_list = nullptr;   // pixels for k_fix_pixels
   size_t cap_fix = 0;
   int2* live_blocks = nullptr;  // the batch's live 8x8 blocks (k_block_cull_compact); cap_samples = cap_live x 64 x spp
+  int* entries = nullptr;       // per live block: ENTRY_K start records of its waves' walks (k_block_entries)
   size_t cap_live = 0;          // blocks
   int* block_slot = nullptr;    // per block of the host's list: slot among the live ones, or -1
   size_t cap_slots = 0;
@@ -483,7 +484,7 @@ extern "C" void rtmi_scene_destroy(rtmi_scene* sc) {
   }
   (void)hipFree(sc->fast.hit_id); (void)hipFree(sc->fast.best_pos); (void)hipFree(sc->fast.rgbf); (void)hipFree(sc->fast.cand);
   (void)hipFree(sc->fast.multi); (void)hipFree(sc->wb.multi); (void)hipFree(sc->fast.live_blocks); (void)hipFree(sc->fast.block_slot);
-  (void)hipFree(sc->fast.fix_list); (void)hipFree(sc->fast.consts);
+  (void)hipFree(sc->fast.fix_list); (void)hipFree(sc->fast.consts); (void)hipFree(sc->fast.entries);
   (void)hipFree(sc->d_objects); (void)hipFree(sc->d_lights); (void)hipFree(sc->d_materials);
   (void)hipFree(sc->d_tris); (void)hipFree(sc->d_planes); (void)hipFree(sc->d_tri_owner);
   (void)hipFree(sc->d_trec); (void)hipFree(sc->d_gst2);
@@ -953,6 +954,14 @@ static bool fast_enabled() {
   }();
   return v;
 }
+// RTMI_BLOCK_ENTRIES=0 (experiments): the walks of that path start at the root instead of the records found per block.
+static bool block_entries_enabled() {
+  static bool v = [] {
+    const char* e = getenv("RTMI_BLOCK_ENTRIES");
+    return !(e && atoi(e) == 0);
+  }();
+  return v;
+}
 // RTMI_FAST_FORCE (tests): bit 0 = every (ray, triangle) pair of such a frame is decided in FP64, bit 1 = every pixel is
 // shaded again in FP64 -- the two fallbacks of the path, each made the rule.
 static int fast_force() {
@@ -996,8 +1005,9 @@ static int32_t ensure_fast_buffers(rtmi_scene* sc, size_t live_blocks, size_t sa
   const size_t samples = live_blocks * samples_per_block;
   if (samples > f.cap_samples || live_blocks > f.cap_live) {
     (void)hipFree(f.hit_id); (void)hipFree(f.best_pos); (void)hipFree(f.rgbf); (void)hipFree(f.cand); (void)hipFree(f.multi);
-    (void)hipFree(f.live_blocks);
+    (void)hipFree(f.live_blocks); (void)hipFree(f.entries);
     f.live_blocks = nullptr;
+    f.entries = nullptr;
     f.cap_live = 0;
     f.multi = nullptr;
     f.cap_multi = 0;
@@ -1021,6 +1031,7 @@ static int32_t ensure_fast_buffers(rtmi_scene* sc, size_t live_blocks, size_t sa
     }
     HIP_TRY(hipMalloc(&f.multi, sizeof(int2) * f.cap_multi));
     HIP_TRY(hipMalloc(&f.live_blocks, sizeof(int2) * live_blocks));
+    HIP_TRY(hipMalloc(&f.entries, sizeof(int) * ENTRY_K * live_blocks));
     f.cap_live = live_blocks;
     f.cap_samples = samples;
   }
@@ -1478,15 +1489,21 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
                          sc->fast.live_blocks, sc->fast.block_slot, fa.cap_live, sc->wb.cnt);
       for (size_t gi = 1; gi < sc->groups.size(); ++gi) {
         TriGroup& g = sc->groups[gi];
+        fa.obj = g.object;
+        fa.init_hit = gi == 1 ? 1 : 0;
+        fa.pos_plane = g.d_pos_plane;
+        fa.pos_mt = g.d_pos_mt;
+        fa.entries = nullptr;
+        if (block_entries_enabled() && g.tree.n_root == 1 && g.n_records < ((size_t)1 << ENTRY_SHIFT) && g.tree.ltop >= 1) {
+          fa.entries = sc->fast.entries;
+          hipLaunchKernelGGL(k_block_entries, dim3((unsigned)(((size_t)fa.cap_live * ENTRY_K + 255) / 256)), dim3(256), 0, st, fcb, fa, (const f2*)g.d_rec, g.tree,
+                             (int)g.n_records, sc->wb.cnt, sc->fast.entries);
+        }
         hipEvent_t* ev;
         if ((rc = next_events(&ev))) return rc;
         HIP_TRY(hipEventRecord(ev[0], st));
         const int par = launch_parity;
         launch_parity ^= 1;
-        fa.obj = g.object;
-        fa.init_hit = gi == 1 ? 1 : 0;
-        fa.pos_plane = g.d_pos_plane;
-        fa.pos_mt = g.d_pos_mt;
         hipLaunchKernelGGL(tree_fast, dim3(fgrid), dim3(256), 0, st, sc->d_sargs + gi, (const f2*)g.d_rec, (const float*)g.d_tedge,
                            (const int*)g.d_slot_pos, par, fcb, fa);
         HIP_TRY(hipEventRecord(ev[3], st));
@@ -1647,7 +1664,7 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
     if (fast) {
       const FastBufs& f = sc->fast;
       sc->pend_work_bytes = (int64_t)(f.cap_samples * (2 * sizeof(int) + sizeof(float4)) + (f.cap_cand + f.cap_multi) * sizeof(int2) +
-                                      f.cap_fix * sizeof(int) + f.cap_live * sizeof(int2) + f.cap_slots * sizeof(int) + f.cap_consts + blk);
+                                      f.cap_fix * sizeof(int) + f.cap_live * (sizeof(int2) + ENTRY_K * sizeof(int)) + f.cap_slots * sizeof(int) + f.cap_consts + blk);
     } else {
       const WorkBufs& w = sc->wb;
       sc->pend_work_bytes = (int64_t)(w.cap_samples * (6 * sizeof(int) + 7 * sizeof(double)) + (w.cap_cand + w.cap_multi) * sizeof(int2) + blk);

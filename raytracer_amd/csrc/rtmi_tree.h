@@ -12,7 +12,8 @@
 //     8-ary tree with no pointers;
 //   * once per frame (k_pack_tree) every triangle that a ray from the camera can hit at all
 //     gets the same cone and edge operands as in the list scan, and every inner node gets a
-//     cone (axis, half-angle) that contains the cones of its children; culled or absent
+//     cone (axis, half-angle) that holds every triangle below it (up to 512 triangles: fitted to
+//     their corners; above that: around the cones of its children); culled or absent
 //     children have the zero vector (never pass), children wider than about 75 degrees are
 //     flagged "always descend";
 //   * k_search_tree walks the tree once per wave (all R*64 rays of a wave start at the camera
@@ -23,7 +24,7 @@
 //     candidates that k_search_exact decides in FP64 (rtx::tri_hit), keeping the lowest list
 //     position per ray.
 //
-// A ray that truly hits a triangle has its direction inside that triangle's cone, hence inside
+// A ray that truly hits a triangle has its direction inside that triangle's cone and inside
 // the cone of every ancestor, so it reaches the leaf: the filter never loses a hit.
 #pragma once
 
@@ -328,6 +329,58 @@ __device__ inline NodeCone merge_cones(const NodeCone* ch, int n_valid, unsigned
   return r;
 }
 
+// The cone of a node of levels 1 to 3 is fitted to the CORNERS below it instead: a ray that hits a triangle has its
+// direction inside the spherical triangle of the three unit vectors from the origin to the corners, and a cone of less
+// than 90 degrees that holds the corners holds that triangle.  So with p the node's axis, cos(half-angle) = the least
+// p.corner over every kept triangle below the node bounds all of them, without the slack of a cone around cones (which
+// reaches to the far side of every child's cone and compounds per level).  node_axis is the first half of merge_cones
+// (kinds, "always" mask, axis = normalised sum of the children's axes); node_finish turns the least p.corner into the cone.
+__device__ inline NodeCone node_axis(const NodeCone* ch, int n_valid, unsigned* always) {
+  NodeCone r;
+  r.ax = r.ay = r.az = 0.0;
+  r.c = 1.0;
+  r.s = 0.0;
+  r.kind = 0;
+  r.pad = 0;
+  unsigned wide = 0;
+  bool any = false;
+  d3 sum = rtx::mk(0.0, 0.0, 0.0);
+  for (int k = 0; k < 8; ++k) {
+    int kind = k < n_valid ? ch[k].kind : 0;
+    if (kind == 2) wide |= 1u << k;
+    if (kind == 1) {
+      any = true;
+      sum = rtx::add(sum, rtx::mk(ch[k].ax, ch[k].ay, ch[k].az));
+    }
+  }
+  *always = wide;
+  if (wide) { r.kind = 2; return r; }
+  if (!any) return r;
+  double len = sqrt(rtx::dp(sum, sum));
+  if (!(len > 1.0e-3)) { r.kind = 2; return r; }  // axes cancel (or NaN): no useful cone
+  d3 p = rtx::divs(sum, len);
+  r.kind = 1;
+  r.ax = p.x; r.ay = p.y; r.az = p.z;
+  return r;
+}
+__device__ inline void node_finish(NodeCone* r, double cmin) {
+  if (r->kind != 1) return;
+  cmin -= 1.0e-12;  // FP64 rounding of the dot products
+  if (!(cmin >= 0.25)) {  // (also NaN)
+    r->kind = 2;
+    r->ax = r->ay = r->az = 0.0;
+    return;
+  }
+  r->c = cmin;
+  r->s = sqrt(fmax(0.0, 1.0 - cmin * cmin));
+}
+// The least p.corner of one triangle for the axis of node `n` (1 when the triangle is not kept or the node has no cone).
+__device__ inline double corner_min(const NodeCone& n, bool has, d3 a, d3 b, d3 c) {
+  if (!has || n.kind != 1) return 1.0;
+  const d3 p = rtx::mk(n.ax, n.ay, n.az);
+  return fmin(rtx::dp(p, a), fmin(rtx::dp(p, b), rtx::dp(p, c)));
+}
+
 // Address of child j's x component inside a record; y and z follow at +2 and +4.
 __device__ inline float* rec_entry(float* rec, int rec_index, int j) {
   return rec + (size_t)rec_index * REC_DWORDS + (j >> 1) * 6 + (j & 1);
@@ -363,6 +416,8 @@ k_pack_tree(const rtmi_triangle* __restrict__ tris, const TriPlane* __restrict__
   const int p = blockIdx.x * TREE_BLOCK + tid;
   NodeCone nc;
   nc.ax = nc.ay = nc.az = 0.0; nc.c = 1.0; nc.s = 0.0; nc.kind = 0; nc.pad = 0;
+  d3 ca = rtx::mk(0.0, 0.0, 0.0), cb = ca, cc = ca;  // unit vectors from the camera to the corners of a kept triangle
+  bool has_corners = false;
   if (p < T.n_slots) {
     const int ti = T.slot_tri[p];
     float e9[EDGE_FLOATS];
@@ -393,6 +448,8 @@ k_pack_tree(const rtmi_triangle* __restrict__ tris, const TriPlane* __restrict__
         nc.ax = axis.x; nc.ay = axis.y; nc.az = axis.z;
         nc.c = cos_t;
         nc.s = sqrt(fmax(0.0, 1.0 - cos_t * cos_t));
+        ca = a; cb = bb; cc = c;
+        has_corners = true;
       } else {
         nc.kind = 2;
       }
@@ -419,45 +476,79 @@ k_pack_tree(const rtmi_triangle* __restrict__ tris, const TriPlane* __restrict__
   l0[tid] = nc;
   __syncthreads();
 
-  // Level L nodes (L = 1, 2, 3) of this workgroup: node j merges the eight nodes of record
-  // (L-1, j); the record gets its "always" mask, and the node's own cone goes into record (L, j/8)
-  // if that level exists.
+  // Level L nodes (L = 1, 2, 3) of this workgroup: node j stands for the eight nodes of record (L-1, j); the record gets
+  // its "always" mask, and the node's own cone goes into record (L, j/8) if that level exists.  Per level: the nodes'
+  // axes (one work-item per node), then every work-item's least p.corner for the axis of its ancestor at that level,
+  // reduced over the 8^L work-items below the node, then the cones.
+  __shared__ double cm1[TREE_BLOCK / 8];
+  __shared__ double cm2[TREE_BLOCK / 64];
+  __shared__ double cm3[TREE_BLOCK / 64];
   NodeCone empty = nc;
   empty.kind = 0;
-  {
-    const int g1 = blockIdx.x * (TREE_BLOCK / 8) + tid;
-    if (tid < TREE_BLOCK / 8) {
-      NodeCone m = empty;
-      if (1 <= T.ltop + 1 && g1 < T.n_nodes[1]) {
-        unsigned always;
-        m = merge_cones(&l0[tid * 8], 8, &always);
-        if (1 <= T.ltop) store_cone(rec_entry(T.rec, T.rec_off[1] + (g1 >> 3), g1 & 7), &m, dir_err);
-        reinterpret_cast<unsigned*>(T.rec)[(size_t)(T.rec_off[0] + g1) * REC_DWORDS + REC_ALWAYS] = always;
-      }
-      l1[tid] = m;
-    }
+  const int g1 = blockIdx.x * (TREE_BLOCK / 8) + tid;
+  const int g2 = blockIdx.x * (TREE_BLOCK / 64) + tid;
+  unsigned always = 0;
+  if (tid < TREE_BLOCK / 8) {
+    NodeCone m = empty;
+    if (1 <= T.ltop + 1 && g1 < T.n_nodes[1]) m = node_axis(&l0[tid * 8], 8, &always);
+    l1[tid] = m;
   }
   __syncthreads();
   {
-    const int g2 = blockIdx.x * (TREE_BLOCK / 64) + tid;
-    if (tid < TREE_BLOCK / 64) {
-      NodeCone m = empty;
-      if (2 <= T.ltop + 1 && g2 < T.n_nodes[2]) {
-        unsigned always;
-        m = merge_cones(&l1[tid * 8], 8, &always);
-        if (2 <= T.ltop) store_cone(rec_entry(T.rec, T.rec_off[2] + (g2 >> 3), g2 & 7), &m, dir_err);
-        reinterpret_cast<unsigned*>(T.rec)[(size_t)(T.rec_off[1] + g2) * REC_DWORDS + REC_ALWAYS] = always;
-      }
-      l2[tid] = m;
-    }
+    double v = corner_min(l1[tid >> 3], has_corners, ca, cb, cc);
+    for (int sh = 1; sh < 8; sh <<= 1) v = fmin(v, __shfl_xor(v, sh));
+    if ((tid & 7) == 0) cm1[tid >> 3] = v;
+  }
+  __syncthreads();
+  if (tid < TREE_BLOCK / 8 && 1 <= T.ltop + 1 && g1 < T.n_nodes[1]) {
+    NodeCone m = l1[tid];
+    node_finish(&m, cm1[tid]);
+    if (1 <= T.ltop) store_cone(rec_entry(T.rec, T.rec_off[1] + (g1 >> 3), g1 & 7), &m, dir_err);
+    reinterpret_cast<unsigned*>(T.rec)[(size_t)(T.rec_off[0] + g1) * REC_DWORDS + REC_ALWAYS] = always;
+    l1[tid] = m;
+  }
+  __syncthreads();
+  if (tid < TREE_BLOCK / 64) {
+    NodeCone m = empty;
+    if (2 <= T.ltop + 1 && g2 < T.n_nodes[2]) m = node_axis(&l1[tid * 8], 8, &always);
+    l2[tid] = m;
+  }
+  __syncthreads();
+  {
+    double v = corner_min(l2[tid >> 6], has_corners, ca, cb, cc);
+    for (int sh = 1; sh < 64; sh <<= 1) v = fmin(v, __shfl_xor(v, sh));
+    if ((tid & 63) == 0) cm2[tid >> 6] = v;
+  }
+  __syncthreads();
+  if (tid < TREE_BLOCK / 64 && 2 <= T.ltop + 1 && g2 < T.n_nodes[2]) {
+    NodeCone m = l2[tid];
+    node_finish(&m, cm2[tid]);
+    if (2 <= T.ltop) store_cone(rec_entry(T.rec, T.rec_off[2] + (g2 >> 3), g2 & 7), &m, dir_err);
+    reinterpret_cast<unsigned*>(T.rec)[(size_t)(T.rec_off[1] + g2) * REC_DWORDS + REC_ALWAYS] = always;
+    l2[tid] = m;
   }
   __syncthreads();
   if (T.ltop + 1 < 3) return;
+  __shared__ NodeCone l3;
+  const int g3 = blockIdx.x;
   if (tid == 0) {
-    const int g3 = blockIdx.x;
+    NodeCone m = empty;
+    if (g3 < T.n_nodes[3]) m = node_axis(l2, 8, &always);
+    l3 = m;
+  }
+  __syncthreads();
+  {
+    double v = corner_min(l3, has_corners, ca, cb, cc);
+    for (int sh = 1; sh < 64; sh <<= 1) v = fmin(v, __shfl_xor(v, sh));
+    if ((tid & 63) == 0) cm3[tid >> 6] = v;
+  }
+  __syncthreads();
+  if (tid == 0) {
     if (g3 < T.n_nodes[3]) {
-      unsigned always;
-      NodeCone m = merge_cones(l2, 8, &always);
+      NodeCone m = l3;
+      double v = cm3[0];
+      for (int w = 1; w < TREE_BLOCK / 64; ++w) v = fmin(v, cm3[w]);
+      node_finish(&m, v);
       if (3 <= T.ltop) store_cone(rec_entry(T.rec, T.rec_off[3] + (g3 >> 3), g3 & 7), &m, dir_err);
       reinterpret_cast<unsigned*>(T.rec)[(size_t)(T.rec_off[2] + g3) * REC_DWORDS + REC_ALWAYS] = always;
       T.nodes[T.node_off[3] + g3] = m;

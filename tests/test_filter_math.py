@@ -47,8 +47,15 @@ def cone_vector(axis, cos_t):
     return w, wide
 
 
+def fit(axes, corners):
+    """node_axis + node_finish (levels 1 to 3 of k_pack_tree): the cone around the normalised sum of the children's axes
+    that holds every corner direction below the node.  corners: [n, 3] unit vectors."""
+    p = unit(axes.sum(axis=0))
+    return p, (corners @ p).min() - 1e-12
+
+
 def merge(axes, cos_c):
-    """merge_cones: cone around the normalised axis sum that contains every child cone."""
+    """merge_cones (levels 4 and up): cone around the normalised axis sum that contains every child cone."""
     p = unit(axes.sum(axis=0))
     ca = axes @ p
     sa = np.linalg.norm(np.cross(np.broadcast_to(p, axes.shape), axes), axis=1)
@@ -94,14 +101,19 @@ def test_cone_tree_and_edge_test_never_reject_a_hit(oracle_mod, scale, offset, r
     axis, cos_t = triangle_cone(v, o)
     w, wide = cone_vector(axis, cos_t)
     m = edge_vectors(v, o)
-    # ancestors: groups of 8 consecutive triangles, groups of 8 of those
+    # ancestors: groups of 8 consecutive triangles and groups of 8 of those, fitted to the corners below them; above
+    # that a cone around the cones (as the levels that span several workgroups are built)
+    corners = unit(v - o)                                                       # [T,3,3]
     groups = [np.arange(i, min(i + 8, len(v))) for i in range(0, len(v), 8)]
-    lvl1 = [merge(axis[g], cos_t[g]) for g in groups]
+    lvl1 = [fit(axis[g], corners[g].reshape(-1, 3)) for g in groups]
     lvl2 = []
     for i in range(0, len(lvl1), 8):
         ax = np.array([p for p, _ in lvl1[i:i + 8]])
-        cs = np.array([c for _, c in lvl1[i:i + 8]])
-        lvl2.append(merge(ax, cs))
+        lvl2.append(fit(ax, corners[i * 8:(i + 8) * 8].reshape(-1, 3)))
+    lvl3 = [merge(np.array([p for p, _ in lvl2]), np.array([c for _, c in lvl2]))]
+    # the fitted cones are no wider than cones around the children's cones
+    for g, (p, c) in zip(groups, lvl1):
+        assert c >= merge(axis[g], cos_t[g])[1] - 1e-9
     total = 0
     for t in range(0, len(v), 2):
         d64 = hitting_rays(oracle_mod, v[t], o, rng, 64)
@@ -111,7 +123,7 @@ def test_cone_tree_and_edge_test_never_reject_a_hit(oracle_mod, scale, offset, r
         total += len(d)
         if not wide[t]:
             assert (dot3_fma(w[t][None], d) >= 1.0).all(), "triangle cone rejected a hit"
-        for (p, c), idx in ((lvl1[t // 8], t // 8), (lvl2[t // 64], t // 64)):
+        for (p, c), idx in ((lvl1[t // 8], t // 8), (lvl2[t // 64], t // 64), (lvl3[0], 0)):
             if c >= 0.25:  # otherwise the node is 'always descend'
                 wn, _ = cone_vector(p[None], np.array([c]))
                 assert (dot3_fma(wn, d) >= 1.0).all(), "an ancestor cone rejected a hit"
