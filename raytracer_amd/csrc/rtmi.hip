@@ -947,6 +947,66 @@ static void frame_basis(const rtmi_camera* cam, int width, int height, FrameCons
 }
 
 // RTMI_FAST=0: frames that qualify for the path without a ray-generation launch take the general path (for comparison).
+// The small uploads of a frame -- constants that change with the camera, the search argument blocks, the cleared
+// counters -- travel as ONE kernel launch whose argument carries the bytes (a few hundred for a loadObjFile scene):
+// separate hipMemsetAsync / hipMemcpyAsync calls cost about 10 us of stream time each, which is what a frame's share
+// of an 8-way tile split can least afford.  Uploads that do not fit the argument go the usual way.
+constexpr int UPLOAD_MAX_SEGS = 6;
+constexpr int UPLOAD_BLOB_WORDS = 832;
+struct UploadBlob {
+  int n_seg;
+  int zero_words;
+  unsigned int* zero_dst;
+  unsigned int* dst[UPLOAD_MAX_SEGS];
+  int off_words[UPLOAD_MAX_SEGS];
+  int words[UPLOAD_MAX_SEGS];
+  unsigned int data[UPLOAD_BLOB_WORDS];
+};
+static_assert(sizeof(UploadBlob) <= 3584, "a kernel argument block holds 4 KB");
+__global__ void __launch_bounds__(256) k_frame_uploads(UploadBlob b) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
+  for (int i = tid; i < b.zero_words; i += nthreads) b.zero_dst[i] = 0u;
+  for (int sgm = 0; sgm < b.n_seg; ++sgm)
+    for (int i = tid; i < b.words[sgm]; i += nthreads) b.dst[sgm][i] = b.data[b.off_words[sgm] + i];
+}
+struct FrameUploads {
+  struct Seg { void* dst; const void* src; size_t bytes; };
+  std::vector<Seg> segs;
+  void* zero_dst = nullptr;
+  size_t zero_bytes = 0;
+  // src must stay untouched until the next upload to dst (the fallback's asynchronous copy reads it after the call returns)
+  void add(void* dst, const void* src, size_t bytes) { if (bytes) segs.push_back({dst, src, bytes}); }
+  void zero(void* dst, size_t bytes) { zero_dst = dst; zero_bytes = bytes; }
+  int32_t flush(hipStream_t st) {
+    if (segs.empty() && !zero_bytes) return RTMI_OK;
+    size_t total = 0;
+    bool words = zero_bytes % 4 == 0 && zero_bytes / 4 <= 0x7fffffff;
+    for (const Seg& g : segs) { total += g.bytes; words = words && g.bytes % 4 == 0; }
+    if (words && segs.size() <= (size_t)UPLOAD_MAX_SEGS && total <= sizeof(unsigned int) * UPLOAD_BLOB_WORDS) {
+      UploadBlob b{};
+      b.n_seg = (int)segs.size();
+      b.zero_words = (int)(zero_bytes / 4);
+      b.zero_dst = static_cast<unsigned int*>(zero_dst);
+      int at = 0;
+      for (size_t i = 0; i < segs.size(); ++i) {
+        b.dst[i] = static_cast<unsigned int*>(segs[i].dst);
+        b.off_words[i] = at;
+        b.words[i] = (int)(segs[i].bytes / 4);
+        memcpy(b.data + at, segs[i].src, segs[i].bytes);
+        at += b.words[i];
+      }
+      hipLaunchKernelGGL(k_frame_uploads, dim3(8), dim3(256), 0, st, b);
+      HIP_TRY(hipGetLastError());
+    } else {
+      if (zero_bytes) HIP_TRY(hipMemsetAsync(zero_dst, 0, zero_bytes, st));
+      for (const Seg& g : segs) HIP_TRY(hipMemcpyAsync(g.dst, g.src, g.bytes, hipMemcpyHostToDevice, st));
+    }
+    segs.clear();
+    zero_bytes = 0;
+    return RTMI_OK;
+  }
+};
+
 static bool fast_enabled() {
   static bool v = [] {
     const char* e = getenv("RTMI_FAST");
@@ -1238,7 +1298,18 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
 
   hipStream_t st = sc->stream;
   HIP_TRY(hipEventRecord(sc->ev_a, st));
-  HIP_TRY(hipMemsetAsync(sc->wb.cnt, 0, sizeof(DevCounters), st));
+  FrameUploads uploads;  // flushed before the first kernel that reads what it carries
+  struct UploadGuard {  // an error return before the flush: the device does not hold what the host-side copies say
+    rtmi_scene* sc;
+    FrameUploads* up;
+    ~UploadGuard() {
+      if (up->segs.empty()) return;
+      sc->genf_uploaded.clear();
+      sc->fast.consts_uploaded.clear();
+      sc->sargs_uploaded.clear();
+    }
+  } upload_guard{sc, &uploads};
+  uploads.zero(sc->wb.cnt, sizeof(DevCounters));
 
   // FP32 pre-test of k_gen (scenes without top-level triangle runs: there every sample goes on to
   // the triangle search anyway).  d' = (ul - cam) + uComponent - vComponent in FP32 differs from
@@ -1273,7 +1344,7 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
       }
       if (gf.size() != sc->genf_uploaded.size() || memcmp(gf.data(), sc->genf_uploaded.data(), sizeof(float4) * gf.size()) != 0) {
         sc->genf_uploaded = gf;  // stays untouched until the next upload: the async copy reads it later
-        HIP_TRY(hipMemcpyAsync(sc->d_genf, sc->genf_uploaded.data(), sizeof(float4) * gf.size(), hipMemcpyHostToDevice, st));
+        uploads.add(sc->d_genf, sc->genf_uploaded.data(), sizeof(float4) * gf.size());
       }
       for (int a = 0; a < 3; ++a) fc.base_f[a] = (float)base[a];
       fc.n_genf = (int)gf.size();
@@ -1335,7 +1406,7 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
     }
     if (cb != sc->fast.consts_uploaded) {
       sc->fast.consts_uploaded = cb;  // stays untouched until the next upload: the async copy reads it later
-      HIP_TRY(hipMemcpyAsync(sc->fast.consts, sc->fast.consts_uploaded.data(), consts_bytes, hipMemcpyHostToDevice, st));
+      uploads.add(sc->fast.consts, sc->fast.consts_uploaded.data(), consts_bytes);
     }
     fa.dir_err = (float)(dir_err * 1.0000002);
     fa.n_materials = std::max(1, sc->n_materials);
@@ -1368,6 +1439,7 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
   // the test is one thread per block
   fc.block_live = nullptr;
   if (fc.n_genf > 0 && !blocks.empty() && !fast) {  // (the other path culls and compacts batch by batch)
+    if ((rc = uploads.flush(st))) return rc;
     hipLaunchKernelGGL(k_block_cull, dim3((unsigned)((blocks.size() + 255) / 256)), dim3(256), 0, st, fc,
                        (const int2*)sc->wb.blocks, (int)blocks.size(), sc->wb.block_live);
     fc.block_live = sc->wb.block_live;
@@ -1439,8 +1511,9 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
       memcmp(sc->sargs_uploaded.data(), sc->h_sargs.data(), sizeof(SearchArgs) * sc->h_sargs.size()) != 0) {
     // staged through a copy that stays untouched until the next upload: the async copy reads it later
     sc->sargs_uploaded = sc->h_sargs;
-    HIP_TRY(hipMemcpyAsync(sc->d_sargs, sc->sargs_uploaded.data(), sizeof(SearchArgs) * sc->groups.size(), hipMemcpyHostToDevice, st));
+    uploads.add(sc->d_sargs, sc->sargs_uploaded.data(), sizeof(SearchArgs) * sc->groups.size());
   }
+  if ((rc = uploads.flush(st))) return rc;
 
   ShadeConst shc;
   for (int a = 0; a < 3; ++a) { shc.cam[a] = fc.cam[a]; shc.ambient[a] = fc.ambient[a]; }
