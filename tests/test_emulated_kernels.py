@@ -434,6 +434,8 @@ FAST_CASES = [
     (1, True, (40, 32, 0.5), {}, {"RTMI_MULTI_CAPACITY": "64"}),              # the list of candidates of rays with several overflows
     (1, True, (72, 56, 0.5), {}, {"RTMI_LIVE_CAPACITY": "3"}),                # more live blocks than the arrays hold: rendered again with more
     (2, False, (64, 48, 0.25), {}, {"RTMI_LIVE_CAPACITY": "2", "RTMI_MAX_BATCH_SAMPLES": "8192", "EMU_CUS": "1"}),
+    (1, True, (40, 32, 0.5), {}, {"RTMI_BLOCK_ENTRIES": "0"}),                # every walk starts at the root
+    (1, True, (56, 40, 0.25), {"_level": 3}, None),                           # 1280 triangles: a tree of four record levels
 ]
 
 
@@ -443,7 +445,8 @@ def test_emulated_frames_without_a_ray_generation_launch(emu, oracle_mod, tmp_pa
     margins or in FP64, FP32 lighting with an error bound, the pixels it cannot settle shaded again in FP64.  Hit ids and
     bytes must be the oracle's, for three camera positions in a row on one scene object (one of them inside the mesh)."""
     n_groups, mats, (W, H, sub), extra, env = FAST_CASES[case]
-    data = bounded_spheres_scene(oracle_mod, n_groups, extra_materials=mats)
+    extra = dict(extra)
+    data = bounded_spheres_scene(oracle_mod, n_groups, extra_materials=mats, level=extra.pop("_level", 2))
     cams = [scenes.make_camera(**scenes.MESH_CAMERA), scenes.make_camera((0.7, 0.4, 3.6), (-0.15, -0.1, -1.0), 7.0),
             scenes.make_camera((0.05, 0.0, 0.3), (0.0, 0.2, -1.0), 3.0), scenes.make_camera(**scenes.MESH_CAMERA)]
     p = scenes.make_params(W, H, sub, flags=_abi.RTMI_FLAG_NO_RAY_STATISTICS, **extra)
@@ -453,6 +456,7 @@ def test_emulated_frames_without_a_ray_generation_launch(emu, oracle_mod, tmp_pa
     names = " ".join(stats)
     overflowed = bool(env and "RTMI_CAND_CAPACITY" in env)  # such a frame is rendered again by the general path's list scan
     assert "k_shade_candidates_fast" in names and "k_resolve_fast" in names and ("k_gen" in names) == overflowed
+    assert ("k_block_entries" in names) == (not (env and env.get("RTMI_BLOCK_ENTRIES") == "0"))
     hits = sum(int(o[2]["primary_hits"]) for o in [oracle_mod.render(data, c, p, threads=8) for c in cams[:1]])
     assert frames[0][2].primary_hits == hits > 0
     force = int((env or {}).get("RTMI_FAST_FORCE", "0"))

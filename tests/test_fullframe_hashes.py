@@ -104,9 +104,10 @@ def test_whole_frame_pixels_only_equals_the_oracles(rt, name):
     sc.close()
 
 
-@pytest.mark.parametrize("force", ["1", "2", "3"])
+@pytest.mark.parametrize("force", ["1", "2", "3", "walks start at the root"])
 def test_pixels_only_fallbacks_made_the_rule(force):
-    """C2 with every pair decided in FP64 (1), every pixel shaded again in FP64 (2), both (3): the same digests."""
+    """C2 with every pair decided in FP64 (1), every pixel shaded again in FP64 (2), both (3), or with the tree walks
+    started at the root instead of the records found per block: the same digests."""
     import subprocess
     import sys
     code = (
@@ -125,7 +126,9 @@ def test_pixels_only_fallbacks_made_the_rule(force):
         "cnt = sc.render_device(scenes.make_camera(**scenes.MESH_CAMERA), p, rgba.data_ptr(), hit.data_ptr())\n"
         "print(json.dumps({'rgba': hashlib.sha256(rgba.cpu().numpy().tobytes()).hexdigest(), 'hit': hashlib.sha256(hit.cpu().numpy().tobytes()).hexdigest(), 'cnt': cnt}))\n"
     ) % (os.path.dirname(HERE), os.path.join(HERE, "golden", "fullframe_hashes.json"))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RTMI_FAST_FORCE=force), capture_output=True, text=True, timeout=300)
+    env = dict(os.environ, RTMI_BLOCK_ENTRIES="0") if not force.isdigit() else dict(os.environ, RTMI_FAST_FORCE=force)
+    force = force if force.isdigit() else "0"
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
     rec = GOLDEN["C2"]
