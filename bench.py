@@ -134,6 +134,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-aux", action="store_true",
                     help="skip the legs after the timed region (reference ray counts, static camera, list scan, form T)")
     ap.add_argument("--no-scan-leg", action="store_true", help="skip the list-scan leg only")
+    ap.add_argument("--no-overlap-leg", action="store_true",
+                    help="skip the two-frames-in-flight leg only (profiling: overlapping frames stretch each other's kernel durations)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-verify", action="store_true",
@@ -806,11 +808,11 @@ def aux_legs(rt, scene, data, params, frame, camera_for, args, level, n_lights):
     out["static_camera"] = {"ms_per_step": round(ms, 4), "steps": 5}
     # the timed frames again with two of them in flight (two scene objects, each with a stream and work buffers of its
     # own: what a rank of a multi-GPU run does): the launches of one frame fill the gaps of the other
-    other = rt.Scene(data, device=scene.device)
+    other = None if args.no_overlap_leg else rt.Scene(data, device=scene.device)
     frames2 = [frame, torch.empty_like(frame)]
     pair, flying, n2 = [scene, other], [], args.steps
     torch.cuda.synchronize()
-    for leg in range(2):  # the first pass warms the second scene up
+    for leg in range(0 if other is None else 2):  # the first pass warms the second scene up
         traced = 0
         t0 = time.perf_counter()
         for i in range(n2):
@@ -821,8 +823,9 @@ def aux_legs(rt, scene, data, params, frame, camera_for, args, level, n_lights):
         while flying:
             traced += flying.pop(0).render_end()["primary_rays_traced"]
         ms = (time.perf_counter() - t0) / n2 * 1e3
-    other.close()
-    out["two_frames_in_flight"] = {"ms_per_step": round(ms, 4), "steps": n2, "mrays_per_s": round(traced / n2 / (ms * 1e-3) / 1e6, 1),
+    if other is not None:
+        other.close()
+        out["two_frames_in_flight"] = {"ms_per_step": round(ms, 4), "steps": n2, "mrays_per_s": round(traced / n2 / (ms * 1e-3) / 1e6, 1),
                                    "note": "same frames as the timed region, frame i+1 enqueued before frame i is waited for"}
     if args.search == "tree" and not args.no_scan_leg:
         p = copy.copy(params)
