@@ -881,15 +881,17 @@ static int32_t ensure_bounded_tree(rtmi_scene* sc) {
 }
 
 // `compacted`: the launch walks the live blocks only (k_search_tree_fast); its waves are all busy, and four rays per
-// lane are the better choice down to an eighth of a 4K frame (measured: 0.27 against 0.32 ms) and for a 1024 x 1024 one.
-static int search_rays_per_lane(bool tree, int nsamples, bool compacted = false) {
+// lane are the better choice down to an eighth of a 4K frame (measured: 0.27 against 0.32 ms) and for a 1024 x 1024 one
+// -- unless the mesh is so fine that neighbouring rays meet different triangles (dense: 1.3 M triangles at 1080p with 4
+// samples per pixel, 1.50 ms with two rays per lane, 1.79 with four).
+static int search_rays_per_lane(bool tree, int nsamples, bool compacted = false, bool dense = false) {
   static int forced = [] {
     const char* e = getenv("RTMI_SEARCH_R");
     int v = e ? atoi(e) : 0;
     return (v == 8 || v == 2 || v == 4) ? v : 0;
   }();
   if (forced) return forced;
-  if (compacted) return 4;
+  if (compacted) return dense ? 2 : 4;
   return tree && nsamples <= (16 << 20) ? 2 : 4;
 }
 // Rays with a single candidate are decided where they are shaded (the default), or by k_search_exact like the others
@@ -1547,11 +1549,8 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
     if (b0 > 0) HIP_TRY(hipMemsetAsync(&sc->wb.cnt->q_child, 0, sizeof(int) * 3, st));  // the first batch starts from the cleared counters
     int grid = (nsamples + 255) / 256;
     if (fast) {
-      const int SRf = search_rays_per_lane(true, nsamples, true);
       // one wave per group of R x 64 samples that the arrays have room for (the live blocks are at most that many)
       const long long room = std::min<long long>((long long)fa.cap_live * (long long)samples_per_block, nsamples);
-      const int fgrid = (int)std::max<long long>(1, (room + 256 * SRf - 1) / (256 * SRf));
-      auto tree_fast = SRf == 8 ? k_search_tree_fast<8> : (SRf == 2 ? k_search_tree_fast<2> : k_search_tree_fast<4>);
       fa.all_blocks = d_blk;
       fa.nsamples = 0;  // the kernels read the live count from the device
       if (b0 > 0) {
@@ -1572,6 +1571,9 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
           hipLaunchKernelGGL(k_block_entries, dim3((unsigned)(((size_t)fa.cap_live * ENTRY_K + 255) / 256)), dim3(256), 0, st, fcb, fa, (const f2*)g.d_rec, g.tree,
                              (int)g.n_records, sc->wb.cnt, sc->fast.entries);
         }
+        const int SRf = search_rays_per_lane(true, nsamples, true, (long long)g.n * 64 > (long long)nsamples);
+        const int fgrid = (int)std::max<long long>(1, (room + 256 * SRf - 1) / (256 * SRf));
+        auto tree_fast = SRf == 8 ? k_search_tree_fast<8> : (SRf == 2 ? k_search_tree_fast<2> : k_search_tree_fast<4>);
         hipEvent_t* ev;
         if ((rc = next_events(&ev))) return rc;
         HIP_TRY(hipEventRecord(ev[0], st));
