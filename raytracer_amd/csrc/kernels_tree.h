@@ -476,19 +476,23 @@ k_search_tree_fast(const SearchArgs* __restrict__ ap, const f2* __restrict__ rec
 // Eight lanes per block: lane j of the group holds entry j of the block's list and tests child j of the record that is
 // being expanded.  All groups of a wave step together (the cross-lane operations are wave-wide); a group that is done
 // idles until the wave's last one is.
+// blocks, n_blocks: the blocks to look at; n_blocks < 0: the live list of k_block_cull_compact, whose length (at most cap)
+// only the device knows.  entries_out (may be null): ENTRY_K entries per block.  live_out (may be null): per block 1 if
+// any record is left that a ray of the block can reach, else 0 -- no ray of the block can hit a triangle of the group.
 __global__ void __launch_bounds__(256)
-k_block_entries(FrameConst fc, FastArgs fa, const f2* __restrict__ rec_all, TreeDev T, int n_records, DevCounters* cnt, int* entries_out) {
+k_block_entries(FrameConst fc, const int2* __restrict__ blocks, int n_blocks, int cap, float dir_err, const f2* __restrict__ rec_all, TreeDev T,
+                int n_records, DevCounters* cnt, int* entries_out, unsigned char* live_out) {
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   const int slot = tid >> 3, j = tid & 7;
   const int lane = threadIdx.x & 63, g0 = lane & ~7;  // first lane of the group
-  const int n_live = min(max(cnt->n_live, 0), fa.cap_live);
-  const bool exists = slot < n_live;
+  const int n_blk = n_blocks >= 0 ? n_blocks : min(max(cnt->n_live, 0), cap);
+  const bool exists = slot < n_blk;
   int e = -1;  // this lane's entry
   double cx = 0.0, cy = 0.0, cz = 0.0, sPhi = 1.0, cPhi = 0.0;
   if (exists) {
     double dx, dy, dz, len, rho;
-    const bool bounded = block_centre(fc, fa.blocks[slot], &dx, &dy, &dz, &len, &rho);
-    sPhi = rho / len + 2.0 * (double)fa.dir_err + 2.0e-6;
+    const bool bounded = block_centre(fc, blocks[slot], &dx, &dy, &dz, &len, &rho);
+    sPhi = rho / len + 2.0 * (double)dir_err + 2.0e-6;
     const bool usable = T.n_root == 1 && bounded && sPhi < 0.5 && T.ltop >= 1;
     cPhi = sqrt(fmax(0.0, 1.0 - sPhi * sPhi));
     cx = dx / len; cy = dy / len; cz = dz / len;
@@ -552,7 +556,11 @@ k_block_entries(FrameConst fc, FastArgs fa, const f2* __restrict__ rec_all, Tree
       }
     }
   }
-  if (exists) entries_out[(size_t)slot * ENTRY_K + j] = e >= 0 ? (e & ~ENTRY_FINAL) : -1;
+  const unsigned left = (unsigned)(__ballot(e >= 0) >> g0) & 0xffu;
+  if (exists) {
+    if (entries_out) entries_out[(size_t)slot * ENTRY_K + j] = e >= 0 ? (e & ~ENTRY_FINAL) : -1;
+    if (live_out && j == 0) live_out[slot] = left ? 1 : 0;
+  }
 }
 
 // One lane per candidate: the reference's own arithmetic in FP64; a hit competes for the ray's

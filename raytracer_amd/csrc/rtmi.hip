@@ -1473,6 +1473,18 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
     memcpy(g.packed_cam, cam->pos, sizeof(g.packed_cam));
   }
 
+  // A scene whose list holds top-level triangle runs and nothing a primary ray could meet besides: the 8x8 blocks that
+  // cannot reach any record of the runs' cone tree hold no hit (k_block_entries); k_gen skips them and k_resolve writes
+  // them black, as for the blocks that k_block_cull clears on scenes of spheres.
+  if (use_tree && !fast && sc->groups[0].n > 0 && sc->dev.n_sphere_like == 0 && !blocks.empty() && block_entries_enabled() &&
+      sc->groups[0].tree.n_root == 1 && sc->groups[0].tree.ltop >= 1 && sc->groups[0].n_records < ((size_t)1 << ENTRY_SHIFT)) {
+    const TriGroup& g0 = sc->groups[0];
+    hipLaunchKernelGGL(k_block_entries, dim3((unsigned)((blocks.size() * ENTRY_K + 255) / 256)), dim3(256), 0, st, fc, (const int2*)sc->wb.blocks,
+                       (int)blocks.size(), (int)blocks.size(), 0.0f, (const f2*)g0.d_rec, g0.tree, (int)g0.n_records, sc->wb.cnt, (int*)nullptr,
+                       sc->wb.block_live);
+    fc.block_live = sc->wb.block_live;
+  }
+
   // argument blocks of the search launches (one per triangle group), uploaded once per frame
   for (size_t gi = 0; gi < sc->groups.size(); ++gi) {
     const TriGroup& g = sc->groups[gi];
@@ -1568,8 +1580,9 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
         fa.entries = nullptr;
         if (block_entries_enabled() && g.tree.n_root == 1 && g.n_records < ((size_t)1 << ENTRY_SHIFT) && g.tree.ltop >= 1) {
           fa.entries = sc->fast.entries;
-          hipLaunchKernelGGL(k_block_entries, dim3((unsigned)(((size_t)fa.cap_live * ENTRY_K + 255) / 256)), dim3(256), 0, st, fcb, fa, (const f2*)g.d_rec, g.tree,
-                             (int)g.n_records, sc->wb.cnt, sc->fast.entries);
+          hipLaunchKernelGGL(k_block_entries, dim3((unsigned)(((size_t)fa.cap_live * ENTRY_K + 255) / 256)), dim3(256), 0, st, fcb,
+                             (const int2*)sc->fast.live_blocks, -1, fa.cap_live, fa.dir_err, (const f2*)g.d_rec, g.tree, (int)g.n_records, sc->wb.cnt,
+                             sc->fast.entries, (unsigned char*)nullptr);
         }
         const int SRf = search_rays_per_lane(true, nsamples, true, (long long)g.n * 64 > (long long)nsamples);
         const int fgrid = (int)std::max<long long>(1, (room + 256 * SRf - 1) / (256 * SRf));
