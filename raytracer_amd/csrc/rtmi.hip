@@ -984,7 +984,11 @@ struct FrameUploads {
     size_t total = 0;
     bool words = zero_bytes % 4 == 0 && zero_bytes / 4 <= 0x7fffffff;
     for (const Seg& g : segs) { total += g.bytes; words = words && g.bytes % 4 == 0; }
-    if (words && segs.size() <= (size_t)UPLOAD_MAX_SEGS && total <= sizeof(unsigned int) * UPLOAD_BLOB_WORDS) {
+    static const bool by_kernel = [] {  // RTMI_UPLOAD_KERNEL=0 (tests, comparisons): always the separate calls
+      const char* e = getenv("RTMI_UPLOAD_KERNEL");
+      return !(e && atoi(e) == 0);
+    }();
+    if (by_kernel && words && segs.size() <= (size_t)UPLOAD_MAX_SEGS && total <= sizeof(unsigned int) * UPLOAD_BLOB_WORDS) {
       UploadBlob b{};
       b.n_seg = (int)segs.size();
       b.zero_words = (int)(zero_bytes / 4);

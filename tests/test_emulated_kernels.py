@@ -435,6 +435,7 @@ FAST_CASES = [
     (1, True, (72, 56, 0.5), {}, {"RTMI_LIVE_CAPACITY": "3"}),                # more live blocks than the arrays hold: rendered again with more
     (2, False, (64, 48, 0.25), {}, {"RTMI_LIVE_CAPACITY": "2", "RTMI_MAX_BATCH_SAMPLES": "8192", "EMU_CUS": "1"}),
     (1, True, (40, 32, 0.5), {}, {"RTMI_BLOCK_ENTRIES": "0"}),                # every walk starts at the root
+    (2, True, (40, 32, 0.5), {}, {"RTMI_UPLOAD_KERNEL": "0"}),                # the frame's small uploads as separate calls
     (1, True, (56, 40, 0.25), {"_level": 3}, None),                           # 1280 triangles: a tree of four record levels
 ]
 
