@@ -693,7 +693,11 @@ def walk_roofline(args, totals, steps):
                 "time (HIP events on the library's stream around this kernel alone).  The walk itself (which records a wave "
                 "visits) is scalar code and is not counted.  peak = packed FP32 (two cone tests per v_pk_fma_f32); the edge test "
                 "is unpacked.  algorithmic_bytes = what must cross HBM: 8 B per ray that is searched (best position and hit id "
-                "initialised) + 8 B per candidate written.  `executed` holds what the hardware did according to the PMC counters.",
+                "initialised) + 8 B per candidate written.  `executed` holds what the hardware did according to the PMC counters.  "
+                "The launch starts each wave's walk at records found once per 8x8 block (k_block_entries), which removed nine in "
+                "ten of the cone tests it used to perform: frac counts the tests that are left, so it fell while the launch got "
+                "faster; the VALU-issue share in `executed` says how busy the launch keeps the vector units with everything it does "
+                "(table lookups, compare-and-vote, candidate emission included).",
     }
 
 
