@@ -153,7 +153,8 @@ static void tree_build_host(const rtmi_triangle* tris, const std::vector<int>& i
 // T = A*A + (2 c.o - |o|^2) and nK = rho^2 + delta - |c|^2; delta = 64*2^-24*(|c|_1 + r_o1)^2 exceeds the
 // FP32 evaluation error of T (about 40*2^-24*(|c|_1+|o|_1)^2).  Coordinates are relative to c0; r_o1
 // bounds |o - c0|_1 over every possible ray origin.  Absent children get nK = -3e38 (never pass),
-// non-finite ones +3e38 (always pass).
+// non-finite ones +3e38 (always pass).  A node's sphere sits at the mean of its children's centres and reaches the
+// farthest corner of the triangles below it.
 //
 // A second block of th.n_records records follows the first, in the same layout: per sphere a cone of normals
 // (ax, ay, az, thr) over the triangles below that node.  A triangle is only hit from its front, normal.direction < 0
@@ -248,7 +249,9 @@ static void tree_sphere_records(const rtmi_triangle* tris, const TreeHost& th, c
     store(0, p, sp);
     cur[p] = sp;
   }
+  long long span = 1;
   for (int L = 1; L <= d.ltop; ++L) {
+    span *= 8;
     std::vector<Sph> next((size_t)d.n_nodes[L]);
     for (int j = 0; j < d.n_nodes[L]; ++j) {
       Sph sp{};
@@ -266,13 +269,26 @@ static void tree_sphere_records(const rtmi_triangle* tris, const TreeHost& th, c
         for (int k = 0; k < 8; ++k) {
           int ch = j * 8 + k;
           if (ch >= d.n_nodes[L - 1] || !cur[ch].valid) continue;
-          double e = 0;
-          for (int a = 0; a < 3; ++a) e += (cur[ch].c[a] - sp.c[a]) * (cur[ch].c[a] - sp.c[a]);
-          double reach = (sqrt(e) + cur[ch].r) * (1.0 + 1e-12);
-          if (reach != reach) bad = true;
-          else if (reach > sp.r) sp.r = reach;
+          if (cur[ch].r != cur[ch].r) bad = true;
         }
-        if (bad) sp.r = NAN;  // stored as "always pass"
+        // The radius reaches the farthest CORNER below the node (a sphere that holds the corners holds the triangles):
+        // tighter than reaching around the children's spheres, whose slack would compound from level to level.
+        const long long p0 = (long long)j * span, p1 = std::min<long long>(p0 + span, d.n_nodes[0]);
+        double r2 = 0;
+        for (long long p = p0; p < p1 && !bad; ++p) {
+          const int ti = th.slot_tri[p];
+          if (ti < 0) continue;
+          for (int q = 0; q < 3; ++q) {
+            double e = 0;
+            for (int a = 0; a < 3; ++a) {
+              const double dv = (tris[ti].v[q][a] - c0[a]) - sp.c[a];
+              e += dv * dv;
+            }
+            if (e != e) bad = true;
+            else if (e > r2) r2 = e;
+          }
+        }
+        sp.r = bad ? NAN : sqrt(r2) * (1.0 + 1e-12);  // NaN is stored as "always pass"
       }
       store(L, j, sp);
       next[j] = sp;

@@ -161,7 +161,7 @@ def test_bounding_spheres_never_reject_a_hit_from_any_origin(oracle_mod):
             # leaf sphere and the sphere of its group of 8
             g = np.arange(t // 8 * 8, min(t // 8 * 8 + 8, len(v)))
             gc = cen[g].mean(axis=0)
-            gr = (np.linalg.norm(cen[g] - gc, axis=1) + rho[g]).max() * (1 + 1e-12)
+            gr = np.linalg.norm((v[g] - c0).reshape(-1, 3) - gc, axis=1).max() * (1 + 1e-12)  # reaches the farthest corner below the node
             for c, r in ((cen[t], rho[t]), (gc, gr)):
                 cf, nk = sphere_entry(c, r)
                 A = fma32(np.broadcast_to(cf[2], d[:, 2].shape), d[:, 2], fma32(np.broadcast_to(cf[1], d[:, 1].shape), d[:, 1],
