@@ -271,21 +271,40 @@ static void tree_sphere_records(const rtmi_triangle* tris, const TreeHost& th, c
           if (ch >= d.n_nodes[L - 1] || !cur[ch].valid) continue;
           if (cur[ch].r != cur[ch].r) bad = true;
         }
-        // The radius reaches the farthest CORNER below the node (a sphere that holds the corners holds the triangles):
-        // tighter than reaching around the children's spheres, whose slack would compound from level to level.
+        // The sphere holds every CORNER below the node (a sphere that holds the corners holds the triangles): tighter
+        // than reaching around the children's spheres, whose slack would compound from level to level.  Its centre
+        // starts at the mean of the children's centres and, for nodes of up to 512 triangles, takes a few steps towards
+        // the farthest corner (Badoiu and Clarkson's approximation of the smallest enclosing ball); the best centre
+        // seen is kept.
         const long long p0 = (long long)j * span, p1 = std::min<long long>(p0 + span, d.n_nodes[0]);
-        double r2 = 0;
-        for (long long p = p0; p < p1 && !bad; ++p) {
-          const int ti = th.slot_tri[p];
-          if (ti < 0) continue;
-          for (int q = 0; q < 3; ++q) {
-            double e = 0;
-            for (int a = 0; a < 3; ++a) {
-              const double dv = (tris[ti].v[q][a] - c0[a]) - sp.c[a];
-              e += dv * dv;
+        auto far2 = [&](const double c[3], double far[3]) {  // squared distance to the farthest corner, and that corner
+          double r2m = -1.0;
+          for (long long p = p0; p < p1; ++p) {
+            const int ti = th.slot_tri[p];
+            if (ti < 0) continue;
+            for (int q = 0; q < 3; ++q) {
+              double e = 0, w[3];
+              for (int a = 0; a < 3; ++a) {
+                w[a] = tris[ti].v[q][a] - c0[a];
+                e += (w[a] - c[a]) * (w[a] - c[a]);
+              }
+              if (e != e) return (double)NAN;
+              if (e > r2m) { r2m = e; far[0] = w[0]; far[1] = w[1]; far[2] = w[2]; }
             }
-            if (e != e) bad = true;
-            else if (e > r2) r2 = e;
+          }
+          return r2m < 0 ? 0.0 : r2m;
+        };
+        double r2 = 0;
+        if (!bad) {
+          double c[3] = {sp.c[0], sp.c[1], sp.c[2]}, far[3] = {0, 0, 0};
+          r2 = far2(c, far);
+          if (r2 != r2) bad = true;
+          const int steps = span <= 512 ? 24 : 0;
+          for (int it = 1; it <= steps && !bad; ++it) {
+            for (int a = 0; a < 3; ++a) c[a] += (far[a] - c[a]) / (double)(it + 1);
+            const double e = far2(c, far);
+            if (e != e || !std::isfinite(c[0] + c[1] + c[2])) break;  // keep what we have
+            if (e < r2) { r2 = e; sp.c[0] = c[0]; sp.c[1] = c[1]; sp.c[2] = c[2]; }
           }
         }
         sp.r = bad ? NAN : sqrt(r2) * (1.0 + 1e-12);  // NaN is stored as "always pass"
