@@ -199,8 +199,32 @@ static void tree_sphere_records(const rtmi_triangle* tris, const TreeHost& th, c
         const double al = sqrt(ax * ax + ay * ay + az * az);
         if (!(al > 1e-9)) continue;
         ax /= al; ay /= al; az /= al;
-        double cmin = 1.0;
-        for (long long p = p0; p < p1; ++p) if (has[p]) cmin = std::min(cmin, ax * nrm[p * 3] + ay * nrm[p * 3 + 1] + az * nrm[p * 3 + 2]);
+        // least cosine between an axis and the normals below the node, and the normal that has it
+        auto least = [&](double x, double y, double z, long long* at) {
+          double c = INFINITY;
+          *at = -1;
+          for (long long p = p0; p < p1; ++p)
+            if (has[p]) {
+              const double dq = x * nrm[p * 3] + y * nrm[p * 3 + 1] + z * nrm[p * 3 + 2];
+              if (dq < c) { c = dq; *at = p; }
+            }
+          return std::min(c, 1.0);
+        };
+        long long far = -1;
+        double cmin = least(ax, ay, az, &far);
+        // the mean normal is not the axis of the narrowest cone: a few steps towards the normal farthest from the axis
+        // (nodes of up to 512 triangles), the best axis kept
+        double bx = ax, by = ay, bz = az;
+        for (int it = 1; it <= (span <= 512 ? 24 : 0) && far >= 0; ++it) {
+          bx += (nrm[far * 3] - bx) / (double)(it + 1);
+          by += (nrm[far * 3 + 1] - by) / (double)(it + 1);
+          bz += (nrm[far * 3 + 2] - bz) / (double)(it + 1);
+          const double bl = sqrt(bx * bx + by * by + bz * bz);
+          if (!(bl > 1e-9)) break;
+          bx /= bl; by /= bl; bz /= bl;
+          const double c = least(bx, by, bz, &far);
+          if (c > cmin) { cmin = c; ax = bx; ay = by; az = bz; }
+        }
         if (!(cmin > 0.1)) continue;  // wider than about 84 degrees: not worth a test
         const double sin_theta = sqrt(std::max(0.0, 1.0 - std::min(cmin, 1.0) * std::min(cmin, 1.0)));
         float* dst = cone + (size_t)(d.rec_off[L] + (j >> 3)) * REC_DWORDS + ((j & 7) >> 1) * 8 + (j & 1);
