@@ -116,6 +116,7 @@ struct FastArgs {
   int fix_cap;
   int force;                  // tests: bit 0 = no pair is accepted by the FP32 margins, bit 1 = every pixel goes to k_fix_pixels
   const int* entries;         // per live block ENTRY_K records where the walks of its waves start (k_block_entries); null: at the root
+  int entry_masks;            // the entries of leaf records carry a mask of the triangles a ray of the block can reach
 };
 
 // Where the walk of a block's waves starts.  Every direction of an 8x8 pixel block lies within a small angle of the
@@ -126,6 +127,9 @@ struct FastArgs {
 constexpr int ENTRY_K = 8;
 constexpr int ENTRY_SHIFT = 27;
 constexpr int ENTRY_FINAL = 1 << 30;  // (inside k_block_entries only) this entry is not expanded any further
+// A leaf record's entry may name the triangles of the record that a ray of the block can reach (the same test, applied
+// to the record's eight triangle cones): record index in the low ENTRY_LEAF_BITS bits, the mask above them.
+constexpr int ENTRY_LEAF_BITS = 19;
 static_assert(ENTRY_K == 8, "k_block_entries keeps a block's list in the eight lanes of a group");
 
 // Every kernel of the path starts with this: the number of live blocks is only known on the device.
@@ -252,7 +256,7 @@ __device__ __forceinline__ void search_tree_body(const SearchArgs* __restrict__ 
         if (nearest) tval[sid[r]] = __builtin_inf();
       }
   }
-  unsigned n_leaf_rec = 0, n_node_rec = 0, n_edge_tri = 0;
+  unsigned n_leaf_tri = 0, n_node_rec = 0, n_edge_tri = 0;
   int fill = 0;
   // per ray of the lane: -1 no candidate so far, -2 several, else the list position of its only one (SearchArgs::singles)
   int pos1[R];
@@ -271,12 +275,12 @@ __device__ __forceinline__ void search_tree_body(const SearchArgs* __restrict__ 
   // A triangle that no ray of the wave passes costs three maxima and a vote; for the others the
   // edge test follows at once, and what remains is a candidate.
   const int n_slots = ap->tree.n_slots, n_records = ap->n_records;
-  auto leaf = [&](int ri) {
+  auto leaf = [&](int ri, unsigned tmask) {  // tmask (wave-uniform): the triangles of the record to look at
     if ((unsigned)(ri * 8) >= (unsigned)n_slots) {  // only a defective record can lead here
       ap->cnt->bug = 3;
       return;
     }
-    ++n_leaf_rec;
+    n_leaf_tri += __popc(tmask);
     const f2* rp = rec + (size_t)(o0 + ri) * (REC_DWORDS / 2);
     f2 cur[12];
 #pragma unroll
@@ -285,6 +289,7 @@ __device__ __forceinline__ void search_tree_body(const SearchArgs* __restrict__ 
     const float* edge = edge_all + (size_t)ri * (8 * EDGE_FLOATS);
 #pragma unroll
     for (int pr = 0; pr < 4; ++pr) {
+      if (!((tmask >> (2 * pr)) & 3u)) continue;
       f2 q[R];
 #pragma unroll
       for (int r = 0; r < R; ++r) { f2 X = {dx[r], dx[r]}; q[r] = cur[pr * 3 + 0] * X; }
@@ -295,6 +300,7 @@ __device__ __forceinline__ void search_tree_body(const SearchArgs* __restrict__ 
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int jj = pr * 2 + h;
+        if (!((tmask >> jj) & 1u)) continue;
         float mq = h ? q[0].y : q[0].x;  // fmaxf drops the NaN of absent rays
 #pragma unroll
         for (int r = 1; r < R; ++r) mq = __builtin_fmaxf(mq, h ? q[r].y : q[r].x);
@@ -375,11 +381,19 @@ __device__ __forceinline__ void search_tree_body(const SearchArgs* __restrict__ 
     // a start is a record (top, ri) with top >= 1, or a leaf record: the latter enters the loop below as the only
     // pending child of its (unevaluated) parent, so that the leaf code exists once
     int top = ltop, ri = t;
+    unsigned start_mask = 0xffu;  // of a start that is a leaf record: its triangles to look at
     if (entries) {
       const int e = __builtin_amdgcn_readfirstlane(entries[t]);
       if (e < 0) break;
       top = (e >> ENTRY_SHIFT) & 7;
       ri = e & ((1 << ENTRY_SHIFT) - 1);
+      if constexpr (FAST) {
+        if (top == 0 && fap->entry_masks) {
+          start_mask = (unsigned)(ri >> ENTRY_LEAF_BITS) & 0xffu;
+          if (start_mask == 0) start_mask = 0xffu;  // (an entry k_block_entries did not get round to)
+          ri &= (1 << ENTRY_LEAF_BITS) - 1;
+        }
+      }
       if (top > ltop) {  // only a defective entry can lead here
         ap->cnt->bug = 6;
         break;
@@ -409,7 +423,7 @@ __device__ __forceinline__ void search_tree_body(const SearchArgs* __restrict__ 
       masks &= ~(1ull << (8 * lvl + c));
       const int child = ri * 8 + c;
       if (lvl == 1) {
-        leaf(child);
+        leaf(child, start_mask);
       } else {
         --lvl;
         ri = child;
@@ -434,7 +448,7 @@ __device__ __forceinline__ void search_tree_body(const SearchArgs* __restrict__ 
 #pragma unroll
   for (int r = 0; r < R; ++r) active += __popcll(__ballot(sid[r] >= 0));
   DevCounters* cnt = ap->cnt;
-  wave_count(cnt, C_TESTS_PRIMARY, lane == 0 ? 8ull * n_leaf_rec * (unsigned long long)active : 0ull);
+  wave_count(cnt, C_TESTS_PRIMARY, lane == 0 ? (unsigned long long)n_leaf_tri * (unsigned long long)active : 0ull);
   wave_count(cnt, C_NODE_TESTS, lane == 0 ? 8ull * n_node_rec * (unsigned long long)active : 0ull);
   wave_count(cnt, C_EDGE_TESTS, lane == 0 ? (unsigned long long)n_edge_tri * (unsigned long long)active : 0ull);
   if constexpr (FAST) wave_count(cnt, C_PRIMARY_TRACED, lane == 0 ? (unsigned long long)active : 0ull);
@@ -481,7 +495,7 @@ k_search_tree_fast(const SearchArgs* __restrict__ ap, const f2* __restrict__ rec
 // any record is left that a ray of the block can reach, else 0 -- no ray of the block can hit a triangle of the group.
 __global__ void __launch_bounds__(256)
 k_block_entries(FrameConst fc, const int2* __restrict__ blocks, int n_blocks, int cap, float dir_err, const f2* __restrict__ rec_all, TreeDev T,
-                int n_records, DevCounters* cnt, int* entries_out, unsigned char* live_out) {
+                int n_records, DevCounters* cnt, int* entries_out, unsigned char* live_out, int leaf_masks) {
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   const int slot = tid >> 3, j = tid & 7;
   const int lane = threadIdx.x & 63, g0 = lane & ~7;  // first lane of the group
@@ -501,8 +515,9 @@ k_block_entries(FrameConst fc, const int2* __restrict__ blocks, int n_blocks, in
   const float* rec = reinterpret_cast<const float*>(rec_all);
   for (int iter = 0; iter < 8 * ENTRY_K; ++iter) {
     // the group's entry of the highest level that may still be expanded: the largest key wins
+    // (with leaf_masks a leaf record's entry is open too, until its triangles have been looked at: last of all)
     const int lvl_e = (e >> ENTRY_SHIFT) & 7;
-    const bool open = e >= 0 && !(e & ENTRY_FINAL) && lvl_e >= 1;
+    const bool open = e >= 0 && !(e & ENTRY_FINAL) && (lvl_e >= 1 || leaf_masks);
     int key = open ? ((lvl_e << 3) | j) : -1;
     for (int sh = 1; sh < 8; sh <<= 1) key = max(key, __shfl_xor(key, sh));
     if (!__any(key >= 0)) break;  // every group of the wave is done
@@ -531,7 +546,11 @@ k_block_entries(FrameConst fc, const int2* __restrict__ blocks, int n_blocks, in
     const unsigned mask = (unsigned)(pb >> g0) & 0xffu;  // children to enter
     const unsigned have = (unsigned)(eb >> g0) & 0xffu;  // entries held
     const int k = __popc(mask), n = __popc(have);
-    const bool expand = active && n - 1 + k <= ENTRY_K;
+    // a leaf record (leaf_masks): its entry makes way for one that carries the mask of the triangles that can be reached
+    // -- or for none, if there is no such triangle
+    const bool is_leaf = active && pick_lvl == 0;
+    const int k_new = is_leaf ? (mask ? 1 : 0) : k;
+    const bool expand = active && (is_leaf || n - 1 + k <= ENTRY_K);
     // the new list: the entries kept (all but the picked one), then the children
     const unsigned kept = expand ? (have & ~(1u << pick)) : have;
     const int n_kept = __popc(kept);
@@ -547,9 +566,10 @@ k_block_entries(FrameConst fc, const int2* __restrict__ blocks, int n_blocks, in
     } else if (expand) {
       if (j < n_kept) {
         e = moved;
-      } else if (j < n_kept + k) {
+      } else if (j < n_kept + k_new) {
         const long long child = (long long)ri * 8 + child_bit;
-        if (child >= (1ll << ENTRY_SHIFT)) { cnt->bug = 8; e = -1; }  // cannot happen: the host leaves such trees to the root
+        if (is_leaf) e = ((int)mask << ENTRY_LEAF_BITS) | ri | ENTRY_FINAL;
+        else if (child >= (1ll << ENTRY_SHIFT)) { cnt->bug = 8; e = -1; }  // cannot happen: the host leaves such trees to the root
         else e = ((pick_lvl - 1) << ENTRY_SHIFT) | (int)child;
       } else {
         e = -1;

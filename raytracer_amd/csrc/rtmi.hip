@@ -1028,6 +1028,15 @@ static bool block_entries_enabled() {
   }();
   return v;
 }
+// RTMI_LEAF_MASKS=0 (experiments): those start records name whole leaf records, never the triangles in them;
+// 2 (tests): always the triangles, also where the mesh is so fine for the frame that it is not worth it.
+static int leaf_masks_mode() {
+  static int v = [] {
+    const char* e = getenv("RTMI_LEAF_MASKS");
+    return e ? atoi(e) : 1;
+  }();
+  return v;
+}
 // RTMI_FAST_FORCE (tests): bit 0 = every (ray, triangle) pair of such a frame is decided in FP64, bit 1 = every pixel is
 // shaded again in FP64 -- the two fallbacks of the path, each made the rule.
 static int fast_force() {
@@ -1485,7 +1494,7 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
     const TriGroup& g0 = sc->groups[0];
     hipLaunchKernelGGL(k_block_entries, dim3((unsigned)((blocks.size() * ENTRY_K + 255) / 256)), dim3(256), 0, st, fc, (const int2*)sc->wb.blocks,
                        (int)blocks.size(), (int)blocks.size(), 0.0f, (const f2*)g0.d_rec, g0.tree, (int)g0.n_records, sc->wb.cnt, (int*)nullptr,
-                       sc->wb.block_live);
+                       sc->wb.block_live, 0);
     fc.block_live = sc->wb.block_live;
   }
 
@@ -1582,11 +1591,17 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
         fa.pos_plane = g.d_pos_plane;
         fa.pos_mt = g.d_pos_mt;
         fa.entries = nullptr;
+        fa.entry_masks = 0;
         if (block_entries_enabled() && g.tree.n_root == 1 && g.n_records < ((size_t)1 << ENTRY_SHIFT) && g.tree.ltop >= 1) {
           fa.entries = sc->fast.entries;
+          // (a leaf record's entry holds its index and a mask of its triangles: trees of up to 4 M triangles)
+          // (not for a mesh so fine that a block reaches most triangles of its records: the masks cost more than they save)
+          fa.entry_masks = leaf_masks_mode() != 0 && (size_t)g.tree.n_slots / 8 < ((size_t)1 << ENTRY_LEAF_BITS) &&
+                                   (leaf_masks_mode() == 2 || !((long long)g.n * 64 > (long long)nsamples))
+                               ? 1 : 0;
           hipLaunchKernelGGL(k_block_entries, dim3((unsigned)(((size_t)fa.cap_live * ENTRY_K + 255) / 256)), dim3(256), 0, st, fcb,
                              (const int2*)sc->fast.live_blocks, -1, fa.cap_live, fa.dir_err, (const f2*)g.d_rec, g.tree, (int)g.n_records, sc->wb.cnt,
-                             sc->fast.entries, (unsigned char*)nullptr);
+                             sc->fast.entries, (unsigned char*)nullptr, fa.entry_masks);
         }
         const int SRf = search_rays_per_lane(true, nsamples, true, (long long)g.n * 64 > (long long)nsamples);
         const int fgrid = (int)std::max<long long>(1, (room + 256 * SRf - 1) / (256 * SRf));
