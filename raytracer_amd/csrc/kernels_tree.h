@@ -280,7 +280,7 @@ __device__ __forceinline__ void search_tree_body(const SearchArgs* __restrict__ 
       ap->cnt->bug = 3;
       return;
     }
-    n_leaf_tri += __popc(tmask);
+    n_leaf_tri += (FAST && R == 4) ? __popc(tmask) : 8;
     const f2* rp = rec + (size_t)(o0 + ri) * (REC_DWORDS / 2);
     f2 cur[12];
 #pragma unroll
@@ -289,7 +289,9 @@ __device__ __forceinline__ void search_tree_body(const SearchArgs* __restrict__ 
     const float* edge = edge_all + (size_t)ri * (8 * EDGE_FLOATS);
 #pragma unroll
     for (int pr = 0; pr < 4; ++pr) {
-      if (!((tmask >> (2 * pr)) & 3u)) continue;
+      if constexpr (FAST && R == 4) {  // (the other instantiations are never given a mask: see the host)
+        if (!((tmask >> (2 * pr)) & 3u)) continue;
+      }
       f2 q[R];
 #pragma unroll
       for (int r = 0; r < R; ++r) { f2 X = {dx[r], dx[r]}; q[r] = cur[pr * 3 + 0] * X; }
@@ -300,7 +302,9 @@ __device__ __forceinline__ void search_tree_body(const SearchArgs* __restrict__ 
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int jj = pr * 2 + h;
-        if (!((tmask >> jj) & 1u)) continue;
+        if constexpr (FAST && R == 4) {
+          if (!((tmask >> jj) & 1u)) continue;
+        }
         float mq = h ? q[0].y : q[0].x;  // fmaxf drops the NaN of absent rays
 #pragma unroll
         for (int r = 1; r < R; ++r) mq = __builtin_fmaxf(mq, h ? q[r].y : q[r].x);
@@ -387,7 +391,7 @@ __device__ __forceinline__ void search_tree_body(const SearchArgs* __restrict__ 
       if (e < 0) break;
       top = (e >> ENTRY_SHIFT) & 7;
       ri = e & ((1 << ENTRY_SHIFT) - 1);
-      if constexpr (FAST) {
+      if constexpr (FAST && R == 4) {
         if (top == 0 && fap->entry_masks) {
           start_mask = (unsigned)(ri >> ENTRY_LEAF_BITS) & 0xffu;
           if (start_mask == 0) start_mask = 0xffu;  // (an entry k_block_entries did not get round to)

@@ -1590,20 +1590,21 @@ static int32_t render_enqueue(rtmi_scene* sc, const rtmi_camera* cam, const rtmi
         fa.init_hit = gi == 1 ? 1 : 0;
         fa.pos_plane = g.d_pos_plane;
         fa.pos_mt = g.d_pos_mt;
+        const int SRf = search_rays_per_lane(true, nsamples, true, (long long)g.n * 64 > (long long)nsamples);
         fa.entries = nullptr;
         fa.entry_masks = 0;
         if (block_entries_enabled() && g.tree.n_root == 1 && g.n_records < ((size_t)1 << ENTRY_SHIFT) && g.tree.ltop >= 1) {
           fa.entries = sc->fast.entries;
           // (a leaf record's entry holds its index and a mask of its triangles: trees of up to 4 M triangles)
-          // (not for a mesh so fine that a block reaches most triangles of its records: the masks cost more than they save)
-          fa.entry_masks = leaf_masks_mode() != 0 && (size_t)g.tree.n_slots / 8 < ((size_t)1 << ENTRY_LEAF_BITS) &&
+          // (not for a mesh so fine that a block reaches most triangles of its records: the masks cost more than they save;
+          // and only the walk with four rays per lane reads them)
+          fa.entry_masks = leaf_masks_mode() != 0 && SRf == 4 && (size_t)g.tree.n_slots / 8 < ((size_t)1 << ENTRY_LEAF_BITS) &&
                                    (leaf_masks_mode() == 2 || !((long long)g.n * 64 > (long long)nsamples))
                                ? 1 : 0;
           hipLaunchKernelGGL(k_block_entries, dim3((unsigned)(((size_t)fa.cap_live * ENTRY_K + 255) / 256)), dim3(256), 0, st, fcb,
                              (const int2*)sc->fast.live_blocks, -1, fa.cap_live, fa.dir_err, (const f2*)g.d_rec, g.tree, (int)g.n_records, sc->wb.cnt,
                              sc->fast.entries, (unsigned char*)nullptr, fa.entry_masks);
         }
-        const int SRf = search_rays_per_lane(true, nsamples, true, (long long)g.n * 64 > (long long)nsamples);
         const int fgrid = (int)std::max<long long>(1, (room + 256 * SRf - 1) / (256 * SRf));
         auto tree_fast = SRf == 8 ? k_search_tree_fast<8> : (SRf == 2 ? k_search_tree_fast<2> : k_search_tree_fast<4>);
         hipEvent_t* ev;

@@ -154,6 +154,8 @@ def run_one(seed, index, oracle, keep_dir=None, tsan=False):
             env["RTMI_FAST_FORCE"] = str(1 + (index // 12) % 3)
         # start records that name triangles although the mesh is fine for the frame (small frames always are), or never
         env["RTMI_LEAF_MASKS"] = "2" if index % 2 == 0 else ("0" if index % 8 == 1 else "1")
+        if index % 2 == 0:
+            env["RTMI_SEARCH_R"] = "4"  # (the walk with four rays per lane is the one that reads them)
     for name, search in SEARCHES.items():
         if nearest and name != "tree":
             continue

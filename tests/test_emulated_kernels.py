@@ -437,8 +437,8 @@ FAST_CASES = [
     (1, True, (40, 32, 0.5), {}, {"RTMI_BLOCK_ENTRIES": "0"}),                # every walk starts at the root
     (2, True, (40, 32, 0.5), {}, {"RTMI_UPLOAD_KERNEL": "0"}),                # the frame's small uploads as separate calls
     (1, True, (56, 40, 0.25), {"_level": 3}, None),                           # 1280 triangles: a tree of four record levels
-    (1, True, (40, 32, 0.5), {}, {"RTMI_LEAF_MASKS": "2"}),                   # start records name the triangles to look at
-    (1, True, (56, 40, 0.25), {"_level": 3}, {"RTMI_LEAF_MASKS": "2", "EMU_SEED": "5"}),
+    (1, True, (40, 32, 0.5), {}, {"RTMI_LEAF_MASKS": "2", "RTMI_SEARCH_R": "4"}),   # start records name the triangles to look at
+    (1, True, (56, 40, 0.25), {"_level": 3}, {"RTMI_LEAF_MASKS": "2", "RTMI_SEARCH_R": "4", "EMU_SEED": "5"}),
     (3, False, (44, 36, 0.5), {}, {"RTMI_LEAF_MASKS": "2", "RTMI_SEARCH_R": "4"}),
 ]
 
