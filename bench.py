@@ -733,15 +733,15 @@ def shade32_roofline(args, totals, steps, n_lights):
                         + os.path.relpath(PMC_FILE, ROOT) + ")",
         "flops_per_hit_algorithmic": flops_hit,
         "hits_per_launch": hits,
-        "algorithmic_bytes_per_launch": (8 + 4 + 24 + 24 + 20) * totals["tri_candidates"] / steps,
+        "algorithmic_bytes_per_launch": (8 + 4 + 20) * totals["tri_candidates"] / steps,
         "avg_launch_ms": round(ms, 4),
         "executed": pmc,
         "note": "achieved = hits x the operations of calculateLighting without secondary rays (192 with 3 lights; division, sqrt "
                 "and pow counted as 1) plus the 69 of Triangle.intersections for the hit's own pair / launch time (HIP events on the "
                 "library's stream around this kernel alone), against the FP32 peak: the kernel evaluates them in FP32 and "
-                "carries a bound on the distance from the FP64 value along, which is not counted.  algorithmic_bytes = per "
-                "candidate the entry 8, the best position 4, table entries 24, plane and material index 24 read, hit id and "
-                "colour with bound 20 written.",
+                "carries a bound on the distance from the FP64 value along, which is not counted.  algorithmic_bytes = what "
+                "must cross HBM per candidate: the entry 8 and the best position 4 read, hit id and colour with bound 20 written "
+                "(the sample tables, planes and material indices it also reads are a few megabytes that stay in the caches).",
     }
 
 
