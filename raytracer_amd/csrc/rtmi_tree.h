@@ -502,6 +502,20 @@ k_pack_tree(const rtmi_triangle* __restrict__ tris, const TriPlane* __restrict__
       double ls = sqrt(rtx::dp(sum, sum));
       d3 axis = rtx::divs(sum, ls);
       double cos_t = fmin(rtx::dp(axis, a), fmin(rtx::dp(axis, bb), rtx::dp(axis, c)));
+      // Narrower cones that hold the three corners, where they exist: the cone through all three (its axis is the normal
+      // of the plane through the corners' unit vectors) and the cones over one side.  Whatever axis is tried, the cone
+      // reaches to the corner farthest from it, so every candidate is a valid cone; the narrowest is kept.
+      {
+        d3 cand[4] = {rtx::cross(rtx::sub(bb, a), rtx::sub(c, a)), rtx::add(a, bb), rtx::add(bb, c), rtx::add(c, a)};
+        for (int k = 0; k < 4; ++k) {
+          const double l = sqrt(rtx::dp(cand[k], cand[k]));
+          if (!(l > 1.0e-12)) continue;
+          d3 ax = rtx::divs(cand[k], l);
+          if (rtx::dp(ax, sum) < 0) ax = rtx::smul(-1.0, ax);
+          const double ck = fmin(rtx::dp(ax, a), fmin(rtx::dp(ax, bb), rtx::dp(ax, c)));
+          if (ck > cos_t) { cos_t = ck; axis = ax; }
+        }
+      }
       if (cos_t - 1.9073486328125e-06 - dir_err >= 0.0625) {  // false for NaN too
         nc.kind = 1;
         nc.ax = axis.x; nc.ay = axis.y; nc.az = axis.z;

@@ -35,8 +35,20 @@ def unit(v):
 def triangle_cone(v, o):
     """axis and cos(theta) of the cone around the three corner directions (k_pack_tree)."""
     a = unit(v - o)                       # [T,3,3]
-    axis = unit(a.sum(axis=1))            # [T,3]
+    total = a.sum(axis=1)
+    axis = unit(total)                    # [T,3]
     cos_t = np.einsum("tkc,tc->tk", a, axis).min(axis=1)
+    # narrower cones where they exist: through all three corners, or over one side; each reaches to its farthest corner
+    cands = [np.cross(a[:, 1] - a[:, 0], a[:, 2] - a[:, 0]), a[:, 0] + a[:, 1], a[:, 1] + a[:, 2], a[:, 2] + a[:, 0]]
+    for cand in cands:
+        length = np.linalg.norm(cand, axis=1)
+        ok = length > 1e-12
+        ax = cand / np.where(ok, length, 1.0)[:, None]
+        ax = np.where((np.einsum("tc,tc->t", ax, total) < 0)[:, None], -ax, ax)
+        ck = np.einsum("tkc,tc->tk", a, ax).min(axis=1)
+        better = ok & (ck > cos_t)
+        axis = np.where(better[:, None], ax, axis)
+        cos_t = np.where(better, ck, cos_t)
     return axis, cos_t
 
 
